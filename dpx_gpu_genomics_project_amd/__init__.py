@@ -1,0 +1,37 @@
+"""dpx_gpu_genomics_project_amd -- MI355X-native pairwise-alignment DP engine (hot path only).
+
+The product is ``libdpxalign.so`` (hand-written HIP kernels for gfx950 behind the C ABI of
+``include/dpx_align.h``) plus the C++ host mirror of the reference's class surface in ``hostcpp/``.
+This Python package is plumbing: a ctypes binding of the C ABI (used by tests/ and bench.py) and the
+synthetic-input generator.  There is no CPU fallback: every compute call raises ``DpxError`` when the
+library or a GPU is missing.
+"""
+from .capi import (  # noqa: F401
+    ALGO_ANW,
+    ALGO_BSW,
+    ALGO_LNW,
+    ALGO_LSW,
+    ALGO_NAMES,
+    MAT_D,
+    MAT_H,
+    MAT_I,
+    SCORE_ONLY,
+    KEEP_MATRICES,
+    Batch,
+    DpxError,
+    Params,
+    SeqPair,
+    device_count,
+    device_info,
+    init,
+    lib_path,
+    load,
+    prim_eval,
+)
+from .synth import SynthBatch, make_batch, parse_pairs_file, write_pairs_file  # noqa: F401
+
+__all__ = [
+    "ALGO_ANW", "ALGO_BSW", "ALGO_LNW", "ALGO_LSW", "ALGO_NAMES", "MAT_D", "MAT_H", "MAT_I", "SCORE_ONLY",
+    "KEEP_MATRICES", "Batch", "DpxError", "Params", "SeqPair", "device_count", "device_info", "init",
+    "lib_path", "load", "prim_eval", "SynthBatch", "make_batch", "parse_pairs_file", "write_pairs_file",
+]

@@ -1,0 +1,429 @@
+/*
+ * dpx_capi.cpp -- implementation of include/dpx_align.h on the HIP runtime (host side of libdpxalign.so).
+ *
+ * Owns device memory, streams and launch geometry; the arithmetic is in dpx_kernels.hip.  There is no CPU
+ * fallback anywhere in this file: without a gfx950 device every entry point fails with DPX_ERR_NO_DEVICE.
+ */
+#include "../../include/dpx_align.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "dpx_kernels.h"
+#include "dpx_layout.h"
+
+namespace {
+
+std::mutex g_mu;
+int g_device = -1;
+thread_local std::string t_err;
+
+int hip_fail(hipError_t e, const char *what) {
+    t_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? DPX_ERR_NOMEM : DPX_ERR_HIP;
+}
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return hip_fail(e__, #call); \
+    } while (0)
+
+int bind_device() {
+    if (g_device < 0) {
+        int rc = dpx_init(0);
+        if (rc != DPX_OK) return rc;
+    }
+    HIP_TRY(hipSetDevice(g_device));
+    return DPX_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct dpx_batch {
+    dpx_params prm{};
+    unsigned flags = 0;
+    size_t numPairs = 0;
+    int R = 8;
+    int planes = 1;
+    bool store = true;
+    bool filled = false;
+    uint64_t cells = 0, matElems = 0, algBytes = 0;
+    int maxN = 0, maxM = 0;
+    std::vector<dpx_pair_dev> pairs; /* host mirror of the device pair table */
+    char *dSeq = nullptr;
+    dpx_pair_dev *dPairs = nullptr;
+    int32_t *dOrder = nullptr;
+    int16_t *dMat = nullptr;
+    int32_t *dScore = nullptr, *dEndRow = nullptr, *dEndCol = nullptr;
+    hipStream_t stream = nullptr;
+    dpx_fill_args args{};
+    size_t ldsBytes = 0;
+};
+
+extern "C" {
+
+int dpx_abi_version(void) { return DPX_ABI_VERSION; }
+
+const char *dpx_strerror(int status) {
+    switch (status) {
+    case DPX_OK: return "ok";
+    case DPX_ERR_INVALID: return "invalid argument";
+    case DPX_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case DPX_ERR_HIP: return "HIP runtime error";
+    case DPX_ERR_RANGE: return "scores of this batch do not fit the int16 matrix cells";
+    case DPX_ERR_NOMEM: return "out of memory";
+    case DPX_ERR_NOT_FILLED: return "batch has not been filled yet";
+    case DPX_ERR_NO_MATRIX: return "batch was created with DPX_SCORE_ONLY";
+    case DPX_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    default: return "unknown status";
+    }
+}
+
+const char *dpx_last_error(void) { return t_err.c_str(); }
+
+int dpx_device_count(int *count) {
+    if (!count) return DPX_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); *count = 0; return DPX_ERR_NO_DEVICE; }
+    *count = n;
+    return DPX_OK;
+}
+
+int dpx_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        t_err = "hipGetDeviceCount found no device";
+        return DPX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return DPX_ERR_INVALID;
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { hip_fail(e, "hipSetDevice"); return DPX_ERR_NO_DEVICE; }
+    g_device = device;
+    return DPX_OK;
+}
+
+int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBytes) {
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    if (name && nameCap) { snprintf(name, nameCap, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (computeUnits) *computeUnits = prop.multiProcessorCount;
+    if (hbmBytes) *hbmBytes = prop.totalGlobalMem;
+    return DPX_OK;
+}
+
+int dpx_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_device = -1;
+    return DPX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ batch */
+
+static int validate_params(const dpx_params *p) {
+    if (!p) return DPX_ERR_INVALID;
+    if (p->algo < DPX_ALGO_LNW || p->algo > DPX_ALGO_BSW) return DPX_ERR_INVALID;
+    if (p->algo == DPX_ALGO_BSW && p->band < 1) return DPX_ERR_INVALID;
+    return DPX_OK;
+}
+
+/* Can every value the algorithm stores for an (m x n) pair be held in an int16 cell? */
+static bool fits_int16(const dpx_params &p, long long m, long long n) {
+    auto ab = [](long long v) { return v < 0 ? -v : v; };
+    const long long lim = 32767;
+    if (p.algo == DPX_ALGO_LSW || p.algo == DPX_ALGO_BSW) {
+        /* 0 <= H <= max(match,0) * min(m,n); the kernel also packs the column into 16 bits */
+        long long top = std::max<long long>(p.match, 0) * std::min(m, n);
+        return top <= lim && n <= 65000;
+    }
+    long long w = std::max({ab(p.match), ab(p.mismatch), ab(p.gapOpen)});
+    if (p.algo == DPX_ALGO_LNW) return (m + n) * w <= lim;
+    w = std::max({w, ab(p.gapExtend), ab((long long)p.gapOpen + p.gapExtend)});
+    return ab(p.gapOpen) + (m + n + 1) * w <= lim;
+}
+
+int dpx_batch_destroy(dpx_batch *b) {
+    if (!b) return DPX_OK;
+    if (g_device >= 0) (void)hipSetDevice(g_device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    (void)hipFree(b->dSeq);
+    (void)hipFree(b->dPairs);
+    (void)hipFree(b->dOrder);
+    (void)hipFree(b->dMat);
+    (void)hipFree(b->dScore);
+    (void)hipFree(b->dEndRow);
+    (void)hipFree(b->dEndCol);
+    delete b;
+    return DPX_OK;
+}
+
+int dpx_batch_create(const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
+                     size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
+    if (!out) return DPX_ERR_INVALID;
+    *out = nullptr;
+    int rc = validate_params(params);
+    if (rc != DPX_OK) return rc;
+    if ((numPairs && (!pairs || !sequences)) || numPairs > 0x7fffffffu) return DPX_ERR_INVALID;
+    rc = bind_device();
+    if (rc != DPX_OK) return rc;
+
+    dpx_batch *b = new (std::nothrow) dpx_batch();
+    if (!b) return DPX_ERR_NOMEM;
+    b->prm = *params;
+    b->flags = flags;
+    b->numPairs = numPairs;
+    b->store = !(flags & DPX_SCORE_ONLY);
+    b->planes = params->algo == DPX_ALGO_ANW ? 3 : 1;
+    b->pairs.resize(numPairs);
+
+    /* geometry, validation */
+    bool ragged = false;
+    for (size_t i = 0; i < numPairs; i++) {
+        const dpx_seq_pair &sp = pairs[firstPair + i];
+        if (sp.referenceSize < 0 || sp.querySize < 0 || sp.referenceIdx < 0 || sp.queryIdx < 0 ||
+            (size_t)sp.referenceIdx + (size_t)sp.referenceSize > numBytes ||
+            (size_t)sp.queryIdx + (size_t)sp.querySize > numBytes) {
+            delete b;
+            return DPX_ERR_INVALID;
+        }
+        if (!fits_int16(*params, sp.querySize, sp.referenceSize)) { delete b; return DPX_ERR_RANGE; }
+        dpx_pair_dev &pd = b->pairs[i];
+        pd.refIdx = sp.referenceIdx; pd.n = sp.referenceSize;
+        pd.qryIdx = sp.queryIdx;     pd.m = sp.querySize;
+        b->maxN = std::max(b->maxN, pd.n);
+        b->maxM = std::max(b->maxM, pd.m);
+        b->cells += (uint64_t)pd.n * (uint64_t)pd.m;
+        if (pd.n != b->pairs[0].n || pd.m != b->pairs[0].m) ragged = true;
+    }
+
+    /* rows per lane: smallest tile that keeps short queries in one stripe, 8 (or DPX_R) otherwise */
+    int R = b->maxM <= 128 ? 2 : b->maxM <= 256 ? 4 : 8;
+    if (const char *env = getenv("DPX_R")) {
+        int v = atoi(env);
+        if (v == 2 || v == 4 || v == 8 || (v == 16 && params->algo != DPX_ALGO_ANW)) R = v;
+    }
+    b->R = R;
+    if (params->algo == DPX_ALGO_BSW) { delete b; return DPX_ERR_UNSUPPORTED; } /* banded kernel: next milestone */
+
+    /* matrix placement + algorithmic bytes: int16 cells incl. borders, sequences, 16 B pair record, 12 B result */
+    uint64_t off = 0;
+    for (size_t i = 0; i < numPairs; i++) {
+        dpx_pair_dev &pd = b->pairs[i];
+        pd.matOff = off;
+        if (b->store) off += dpx_tiled_elems(pd.m, pd.n, R, b->planes);
+        b->algBytes += (uint64_t)pd.m + (uint64_t)pd.n + 16u + 12u;
+        if (b->store) b->algBytes += 2ull * (uint64_t)b->planes * (uint64_t)(pd.m + 1) * (uint64_t)(pd.n + 1);
+    }
+    b->matElems = off;
+
+    /* LDS per wave: edge row(s) of int16 [n+2] + staged reference [n+128] */
+    const size_t edgeBytes = align_up((size_t)(b->maxN + 2) * 2, 16);
+    const size_t nEdges = params->algo == DPX_ALGO_ANW ? 2 : 1;
+    const size_t refBytes = align_up((size_t)b->maxN + 128, 16);
+    const size_t perWave = edgeBytes * nEdges + refBytes;
+    b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
+    if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
+
+#define CREATE_TRY(call)                                                      \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) { int r__ = hip_fail(e__, #call); dpx_batch_destroy(b); return r__; } \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void **)&b->dSeq, std::max<size_t>(numBytes, 16)));
+    CREATE_TRY(hipMalloc((void **)&b->dPairs, std::max<size_t>(numPairs, 1) * sizeof(dpx_pair_dev)));
+    CREATE_TRY(hipMalloc((void **)&b->dScore, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void **)&b->dEndRow, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void **)&b->dEndCol, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
+    if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
+    if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
+    if (b->store && b->matElems) CREATE_TRY(hipMalloc((void **)&b->dMat, b->matElems * sizeof(int16_t)));
+    if (ragged) { /* longest-processing-time-first launch order evens out the tail of a ragged batch */
+        std::vector<int32_t> order(numPairs);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+            return (uint64_t)b->pairs[x].m * b->pairs[x].n > (uint64_t)b->pairs[y].m * b->pairs[y].n;
+        });
+        CREATE_TRY(hipMalloc((void **)&b->dOrder, numPairs * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(b->dOrder, order.data(), numPairs * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+#undef CREATE_TRY
+
+    dpx_fill_args &a = b->args;
+    a.seq = b->dSeq;
+    a.pairs = b->dPairs;
+    a.order = b->dOrder;
+    a.numPairs = (int32_t)numPairs;
+    a.match = params->match; a.mismatch = params->mismatch;
+    a.gapOpen = params->gapOpen; a.gapExtend = params->gapExtend; a.band = params->band;
+    a.mat = b->dMat;
+    a.score = b->dScore; a.endRow = b->dEndRow; a.endCol = b->dEndCol;
+    a.ldsPerWave = (uint32_t)perWave;
+    a.ldsEdge2Off = (uint32_t)edgeBytes;
+    a.ldsRefOff = (uint32_t)(edgeBytes * nEdges);
+    *out = b;
+    return DPX_OK;
+}
+
+int dpx_batch_fill(dpx_batch *b, void *stream) {
+    if (!b) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    HIP_TRY(dpx_launch_fill(b->args, b->prm.algo, b->R, b->store, b->ldsBytes, s));
+    b->filled = true;
+    return DPX_OK;
+}
+
+int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
+    if (!b || repeats < 1 || !usecPerFill) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, b->stream));
+    for (int i = 0; i < repeats; i++) {
+        hipError_t e = dpx_launch_fill(b->args, b->prm.algo, b->R, b->store, b->ldsBytes, b->stream);
+        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hip_fail(e, "dpx_launch_fill"); }
+    }
+    HIP_TRY(hipEventRecord(e1, b->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *usecPerFill = (double)ms * 1000.0 / repeats;
+    b->filled = true;
+    return DPX_OK;
+}
+
+int dpx_batch_sync(dpx_batch *b) {
+    if (!b) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DPX_OK;
+}
+
+int dpx_batch_device_results(dpx_batch *b, void **dScores, void **dEndRow, void **dEndCol) {
+    if (!b) return DPX_ERR_INVALID;
+    if (dScores) *dScores = b->dScore;
+    if (dEndRow) *dEndRow = b->dEndRow;
+    if (dEndCol) *dEndCol = b->dEndCol;
+    return DPX_OK;
+}
+
+int dpx_batch_results(dpx_batch *b, int32_t *scores, int32_t *endRow, int32_t *endCol) {
+    if (!b) return DPX_ERR_INVALID;
+    if (!b->filled) return DPX_ERR_NOT_FILLED;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t bytes = b->numPairs * sizeof(int32_t);
+    if (bytes) {
+        if (scores) HIP_TRY(hipMemcpy(scores, b->dScore, bytes, hipMemcpyDeviceToHost));
+        if (endRow) HIP_TRY(hipMemcpy(endRow, b->dEndRow, bytes, hipMemcpyDeviceToHost));
+        if (endCol) HIP_TRY(hipMemcpy(endCol, b->dEndCol, bytes, hipMemcpyDeviceToHost));
+    }
+    return DPX_OK;
+}
+
+int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
+    if (!b || !out || pair >= b->numPairs || which < 0 || which >= b->planes) return DPX_ERR_INVALID;
+    if (!b->store) return DPX_ERR_NO_MATRIX;
+    if (!b->filled) return DPX_ERR_NOT_FILLED;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    const dpx_pair_dev &pd = b->pairs[pair];
+    const size_t total = (size_t)(pd.m + 1) * (size_t)(pd.n + 1);
+    int16_t *dOut = nullptr;
+    HIP_TRY(hipMalloc((void **)&dOut, total * sizeof(int16_t)));
+    hipError_t e = dpx_launch_export(b->dMat, pd, b->prm.algo, b->R, b->planes, which, b->prm.gapOpen, b->prm.gapExtend,
+                                     b->prm.band, dOut, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, total * sizeof(int16_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return hip_fail(e, "dpx_batch_matrix");
+    return DPX_OK;
+}
+
+int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine, char *qryLine, int32_t *len) {
+    (void)b; (void)pair; (void)refLine; (void)relLine; (void)qryLine; (void)len;
+    return DPX_ERR_UNSUPPORTED; /* next milestone */
+}
+
+int dpx_batch_info(dpx_batch *b, size_t *numPairs, uint64_t *cells, uint64_t *matrixBytes, uint64_t *algorithmicBytes) {
+    if (!b) return DPX_ERR_INVALID;
+    if (numPairs) *numPairs = b->numPairs;
+    if (cells) *cells = b->cells;
+    if (matrixBytes) *matrixBytes = b->matElems * sizeof(int16_t);
+    if (algorithmicBytes) *algorithmicBytes = b->algBytes;
+    return DPX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ one-shot */
+
+int dpx_align_batch(const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
+                    size_t numPairs, int32_t *scores, int32_t *endRow, int32_t *endCol, int16_t **H, int16_t **I,
+                    int16_t **D) {
+    const bool wantMat = H || I || D;
+    dpx_batch *b = nullptr;
+    int rc = dpx_batch_create(params, sequences, numBytes, pairs, 0, numPairs, wantMat ? DPX_KEEP_MATRICES : DPX_SCORE_ONLY, &b);
+    if (rc != DPX_OK) return rc;
+    rc = dpx_batch_fill(b, nullptr);
+    if (rc == DPX_OK) rc = dpx_batch_results(b, scores, endRow, endCol);
+    for (size_t p = 0; rc == DPX_OK && wantMat && p < numPairs; p++) {
+        if (H && H[p]) rc = dpx_batch_matrix(b, p, DPX_MAT_H, H[p]);
+        if (rc == DPX_OK && I && I[p] && b->planes == 3) rc = dpx_batch_matrix(b, p, DPX_MAT_I, I[p]);
+        if (rc == DPX_OK && D && D[p] && b->planes == 3) rc = dpx_batch_matrix(b, p, DPX_MAT_D, D[p]);
+    }
+    dpx_batch_destroy(b);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ primitives */
+
+int dpx_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
+                  uint32_t *result, uint32_t *pred) {
+    if (count && (!op || !a || !b || !c || !result || !pred)) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    if (!count) return DPX_OK;
+    void *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes = count * 4;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipMalloc(&d[i], bytes);
+    if (e == hipSuccess) e = hipMemcpy(d[0], op, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d[1], a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d[2], b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d[3], c, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = dpx_launch_prim_eval((const int32_t *)d[0], (const uint32_t *)d[1], (const uint32_t *)d[2], (const uint32_t *)d[3],
+                                 count, (uint32_t *)d[4], (uint32_t *)d[5], nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(result, d[4], bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pred, d[5], bytes, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 6; i++) (void)hipFree(d[i]);
+    if (e != hipSuccess) return hip_fail(e, "dpx_prim_eval");
+    return DPX_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,38 @@
+/* dpx_kernels.h -- interface between the C-ABI layer (dpx_capi.cpp) and the HIP kernels (dpx_kernels.hip). */
+#ifndef DPX_KERNELS_H
+#define DPX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpx_layout.h"
+
+/* same numbering as dpx_algo in include/dpx_align.h */
+#define DPX_K_LNW 0
+#define DPX_K_LSW 1
+#define DPX_K_ANW 2
+#define DPX_K_BSW 3
+
+/* one wave per pair; DPX_FILL_THREADS/64 independent waves share a workgroup (no barriers between them) */
+#define DPX_FILL_THREADS 256
+
+typedef struct dpx_fill_args {
+    const char *seq;            /* flat sequence bytes (device copy of parseInput's buffer) */
+    const dpx_pair_dev *pairs;  /* per-pair geometry + matrix offset */
+    const int32_t *order;       /* optional launch order (longest pairs first) or NULL */
+    int32_t numPairs;
+    int32_t match, mismatch, gapOpen, gapExtend, band;
+    int16_t *mat;               /* matrix pool (int16, engine layout) or NULL when score-only */
+    int32_t *score, *endRow, *endCol;
+    uint32_t ldsPerWave;        /* bytes of dynamic LDS per wave */
+    uint32_t ldsEdge2Off;       /* ANW: offset of the second edge row (D) */
+    uint32_t ldsRefOff;         /* offset of the staged reference characters */
+} dpx_fill_args;
+
+hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
+hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
+                             int gapExtend, int band, int16_t *out, hipStream_t stream);
+hipError_t dpx_launch_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
+                                uint32_t *res, uint32_t *pred, hipStream_t stream);
+
+#endif

@@ -1,0 +1,522 @@
+/*
+ * dpx_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the pairwise-alignment DP fill.
+ *
+ * One 64-lane wavefront per alignment pair.  Lane l owns R consecutive query rows of a 64*R-row stripe and
+ * sweeps the reference columns with a skew of one column per lane, so the wave is always on one anti-diagonal
+ * (of R-row tiles).  Per step and lane:
+ *   - `up` of the lane's top row comes from the previous lane's bottom row through ONE DPP move
+ *     (v_mov_b32_dpp wave_shr:1 -- the reference's __shfl_up_sync, cuda/LNW/LinearNeedlemanWunschV12.cu:149);
+ *     the diagonal is last step's `up`, carried in a register (the V10 trick, V10.cu:157-162);
+ *   - the R cells of the lane are chained in registers (left/diag/up never touch memory);
+ *   - the stripe's bottom row goes to LDS for the next stripe (V12.cu:110-113,141-143: warpEdgeScore);
+ *   - the cell update is v_cmp/v_cndmask + v_add + v_max + v_add + v_max3_i32 (FakeDPX __vibmax/__vimax3,
+ *     c++/FakeDPX.cpp:11-13,145-153; the >= predicates are not needed here because the traceback recomputes
+ *     directions from the stored scores with the same rule);
+ *   - the wave's R x 64 scores of this step leave as one fully coalesced int16 store (dpx_layout.h).
+ * No MFMA (integer max-plus recurrence), no LDS transposes, no atomics.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpx_kernels.h"
+#include "dpx_layout.h"
+#include "dpx_prims.hpp"
+
+namespace {
+
+using dpx::pack_lo16;
+using dpx::wave_shr1;
+using dpx::wave_shl1;
+
+/* ---- coalesced tile store: R int32 scores -> R int16, 2*R bytes per lane, lanes contiguous ---- */
+template <int R>
+__device__ __forceinline__ void store_tile(int16_t *dst, const int (&v)[R]) {
+    if constexpr (R == 1) {
+        *dst = (int16_t)v[0];
+    } else if constexpr (R == 2) {
+        *reinterpret_cast<uint32_t *>(dst) = pack_lo16(v[0], v[1]);
+    } else if constexpr (R == 4) {
+        uint2 w;
+        w.x = pack_lo16(v[0], v[1]);
+        w.y = pack_lo16(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(dst) = w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 8; q++) {
+            uint4 w;
+            w.x = pack_lo16(v[8 * q + 0], v[8 * q + 1]);
+            w.y = pack_lo16(v[8 * q + 2], v[8 * q + 3]);
+            w.z = pack_lo16(v[8 * q + 4], v[8 * q + 5]);
+            w.w = pack_lo16(v[8 * q + 6], v[8 * q + 7]);
+            reinterpret_cast<uint4 *>(dst)[q] = w;
+        }
+    }
+}
+
+/* 64-lane max-reduction of a 64-bit key (once per pair; cost irrelevant) */
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+/* =====================================================================================================
+ * Linear-gap fill: LinearNeedlemanWunsch (LOCAL = false) and LinearSmithWaterman (LOCAL = true).
+ *   NW cell (c++/LinearNeedlemanWunsch.cpp:105-128):  H = max(left+g, max(up+g, diag+s))
+ *   SW cell (c++/LinearSmithWaterman.cpp:82-103):     H = max(0, max(up+g, left+g, diag+s))
+ * ===================================================================================================== */
+template <int R, bool LOCAL>
+struct LinState {
+    int Hl[R];        /* H[row][j-1] of the lane's R rows (the "left" values, then overwritten by H[row][j]) */
+    int qc[R];        /* query characters of the lane's rows */
+    unsigned key[R];  /* SW: per-row running max of (H << 16 | 0xFFFF - j): max score, then smallest column */
+    int dtop;         /* H[row0][j-1]: diagonal of the lane's top row */
+};
+
+template <int R, bool LOCAL, bool STORE, bool MASKED>
+__device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
+                                         const bool laneHasRows, const int match, const int mismatch, const int gap,
+                                         const int e0, const int rc, int16_t *edge, const bool writeEdge,
+                                         int16_t *tileDst) {
+    const int j = t - lane + 1;
+    /* cross-lane traffic happens with all lanes enabled: a finished lane must still feed its neighbour */
+    const int upin = wave_shr1(st.Hl[R - 1], e0);
+    bool active = true;
+    if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
+    if (active) {
+        int u = upin, d = st.dtop;
+        const unsigned negj = 0xFFFFu - (unsigned)j;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int left = st.Hl[r];
+            const int s = (st.qc[r] == rc) ? match : mismatch;
+            const int g = max(u, left) + gap;
+            int h;
+            if constexpr (LOCAL) h = max(max(g, d + s), 0); /* v_max3_i32 */
+            else h = max(g, d + s);
+            d = left;
+            u = h;
+            st.Hl[r] = h;
+            if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)h << 16) | negj);
+        }
+        st.dtop = upin;
+        if constexpr (STORE) store_tile<R>(tileDst, st.Hl);
+        if (writeEdge && lane == 63) edge[j] = (int16_t)st.Hl[R - 1];
+    }
+}
+
+template <int R, bool LOCAL, bool STORE>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* wave-uniform: everything per-pair lives in SGPRs */
+    if (p >= a.numPairs) return;
+    if (a.order) p = a.order[p];
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m;
+    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+
+    if (m <= 0 || n <= 0) { /* empty sequence: only borders exist */
+        if (lane == 0) {
+            a.score[p] = LOCAL ? 0 : (m <= 0 ? n * gap : m * gap);
+            a.endRow[p] = LOCAL ? 0 : max(m, 0);
+            a.endCol[p] = LOCAL ? 0 : max(n, 0);
+        }
+        return;
+    }
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
+    int16_t *edge = reinterpret_cast<int16_t *>(my); /* edge[j], j = 0..n+1: H of the row above the current stripe */
+    unsigned char *refl = my + a.ldsRefOff;           /* refl[64 + (j-1)], 64 bytes of slack either side */
+    for (int x = lane; x < n; x += 64) refl[64 + x] = ref[x];
+    /* row-0 border (LinearNeedlemanWunsch.cpp:38-41; all zero for SW) is the first stripe's "row above" */
+    for (int x = lane; x <= n + 1; x += 64) edge[x] = (int16_t)(LOCAL ? 0 : x * gap);
+
+    int16_t *Hp = a.mat + pr.matOff;
+    const int W = n + 63;
+    const int S = dpx_tiled_stripes(m, R);
+
+    int bestv = 0, bestrow = 0, bestcol = 0;
+    LinState<R, LOCAL> st;
+
+    for (int k = 0; k < S; k++) {
+        const int base = k * 64 * R;
+        const int row0 = base + lane * R; /* rows above the lane's first row */
+        const int nrows = min(max(m - row0, 0), R);
+        const bool laneHasRows = nrows > 0;
+        const bool hasNext = (k + 1 < S);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+            st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
+            st.key[r] = 0u;
+        }
+        st.dtop = LOCAL ? 0 : row0 * gap;
+        int16_t *tile = Hp + ((size_t)k * (size_t)W * 64u + (size_t)lane) * R;
+
+        /* software pipeline: the LDS reads of step t+1 (reference character of the lane's next column, and
+         * lane 0's `up` from the edge row) are issued before the arithmetic of step t */
+        const unsigned char *rp = refl + 64 - lane; /* rp[t] = reference character of column j = t - lane + 1 */
+        int rcN = rp[0];
+        int e0N = edge[1];
+#define DPX_LIN_STEP(MASKED_, HASROWS_)                                                                              \
+        {                                                                                                             \
+            const int rc = rcN, e0 = e0N;                                                                             \
+            rcN = rp[t + 1];                                                                                          \
+            e0N = edge[min(t + 2, n + 1)];                                                                            \
+            lin_step<R, LOCAL, STORE, MASKED_>(st, t, lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, hasNext, \
+                                               tile + (size_t)t * 64u * R);                                          \
+        }
+        const bool fast = (base + 64 * R <= m) && (n >= 64);
+        if (fast) {
+            int t = 0;
+            for (; t < 63; t++) DPX_LIN_STEP(true, true)
+            for (; t < n; t++) DPX_LIN_STEP(false, true)
+            for (; t < W; t++) DPX_LIN_STEP(true, true)
+        } else {
+            for (int t = 0; t < W; t++) DPX_LIN_STEP(true, laneHasRows)
+        }
+#undef DPX_LIN_STEP
+
+        if constexpr (LOCAL) {
+            /* rows ascend with r and with k: a strict '>' keeps the first row holding the lane's maximum */
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int hv = (int)(st.key[r] >> 16);
+                if (r < nrows && hv > bestv) {
+                    bestv = hv;
+                    bestrow = row0 + 1 + r;
+                    bestcol = 0xFFFF - (int)(st.key[r] & 0xFFFFu);
+                }
+            }
+        }
+    }
+
+    if constexpr (LOCAL) {
+        /* first strict maximum in row-major order (c++/LinearSmithWaterman.cpp:145-157):
+         * max score, then smallest row; the lane already holds the smallest column of that row */
+        const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
+        const unsigned long long top = wave_max_u64(mine);
+        if ((int)(top >> 32) == 0) {
+            if (lane == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
+        } else if (mine == top) { /* rows are unique per lane, so exactly one lane matches */
+            a.score[p] = bestv;
+            a.endRow[p] = bestrow;
+            a.endCol[p] = bestcol;
+        }
+    } else {
+        /* score = H[m][n] (LinearNeedlemanWunsch.cpp:176): after the last stripe Hl[] holds column n */
+        const int lastBase = (S - 1) * 64 * R;
+        const int lm = (m - 1 - lastBase) / R, rm = (m - 1 - lastBase) % R;
+        if (lane == lm) {
+            int v = st.Hl[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+            a.score[p] = v;
+            a.endRow[p] = m;
+            a.endCol[p] = n;
+        }
+    }
+}
+
+/* =====================================================================================================
+ * Affine-gap (Gotoh) global fill: AffineNeedlemanWunsch (c++/AffineNeedlemanWunsch.cpp:167-240).
+ *   D[i][j] = (i==1) ? H[i-1][j]+o+e : max(H[i-1][j]+o+e, D[i-1][j]+e)      vertical gap   (:185-197)
+ *   I[i][j] = (j==1) ? H[i][j-1]+o+e : max(H[i][j-1]+o+e, I[i][j-1]+e)      horizontal gap (:201-213)
+ *   H[i][j] = max(I, max(D, H[i-1][j-1]+s))                                                (:229-236)
+ * The i==1 / j==1 special cases are expressed by virtual borders D[0][j] = I[i][0] = DPX_NEG, which gives the
+ * identical values for every stored cell.  Three int16 planes (H, I, D) are written per step.
+ * ===================================================================================================== */
+template <int R>
+struct AffState {
+    int Hl[R], Il[R]; /* H[row][j-1], I[row][j-1] */
+    int Dl[R];        /* D[row][j] just computed (needed only for the store and the lane hand-off) */
+    int qc[R];
+    int dtop;
+};
+
+template <int R, bool STORE, bool MASKED>
+__device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
+                                         const int match, const int mismatch, const int oe, const int e, const int e0H,
+                                         const int e0D, const int rc, int16_t *edgeH, int16_t *edgeD,
+                                         const bool writeEdge, int16_t *tileDst) {
+    const int j = t - lane + 1;
+    const int upH = wave_shr1(st.Hl[R - 1], e0H);
+    const int upD = wave_shr1(st.Dl[R - 1], e0D);
+    bool active = true;
+    if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
+    if (active) {
+        int uH = upH, uD = upD, d = st.dtop;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int lH = st.Hl[r];
+            const int s = (st.qc[r] == rc) ? match : mismatch;
+            const int Dn = max(uH + oe, uD + e);
+            const int In = max(lH + oe, st.Il[r] + e);
+            const int h = max(max(Dn, d + s), In); /* v_max3_i32 */
+            d = lH;
+            uH = h;
+            uD = Dn;
+            st.Hl[r] = h;
+            st.Il[r] = In;
+            st.Dl[r] = Dn;
+        }
+        st.dtop = upH;
+        if constexpr (STORE) {
+            store_tile<R>(tileDst, st.Hl);
+            store_tile<R>(tileDst + 64 * R, st.Il);
+            store_tile<R>(tileDst + 128 * R, st.Dl);
+        }
+        if (writeEdge && lane == 63) {
+            edgeH[j] = (int16_t)st.Hl[R - 1];
+            edgeD[j] = (int16_t)st.Dl[R - 1];
+        }
+    }
+}
+
+template <int R, bool STORE>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    if (p >= a.numPairs) return;
+    if (a.order) p = a.order[p];
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m;
+    const int match = a.match, mismatch = a.mismatch;
+    const int o = a.gapOpen, e = a.gapExtend, oe = o + e;
+
+    if (m <= 0 || n <= 0) {
+        if (lane == 0) { /* H[m][n] on the border: 0 at the origin, else o + len*e (AffineNeedlemanWunsch.cpp:43-53) */
+            const int len = m <= 0 ? max(n, 0) : m;
+            a.score[p] = len <= 0 ? 0 : o + len * e;
+            a.endRow[p] = max(m, 0);
+            a.endCol[p] = max(n, 0);
+        }
+        return;
+    }
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
+    int16_t *edgeH = reinterpret_cast<int16_t *>(my);
+    int16_t *edgeD = reinterpret_cast<int16_t *>(my + a.ldsEdge2Off);
+    unsigned char *refl = my + a.ldsRefOff;
+    for (int x = lane; x < n; x += 64) refl[64 + x] = ref[x];
+    /* row-0 border H[0][j] = o + j*e (AffineNeedlemanWunsch.cpp:50-53); D[0][j] is the virtual DPX_NEG (k == 0 below) */
+    for (int x = lane; x <= n + 1; x += 64) { edgeH[x] = (int16_t)(o + x * e); edgeD[x] = 0; }
+
+    int16_t *Mp = a.mat + pr.matOff;
+    const int W = n + 63;
+    const int S = dpx_tiled_stripes(m, R);
+    AffState<R> st;
+
+    for (int k = 0; k < S; k++) {
+        const int base = k * 64 * R;
+        const int row0 = base + lane * R;
+        const int nrows = min(max(m - row0, 0), R);
+        const bool laneHasRows = nrows > 0;
+        const bool hasNext = (k + 1 < S);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+            st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (:43-46) */
+            st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
+            st.Dl[r] = DPX_NEG;
+        }
+        st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
+        int16_t *tile = Mp + ((size_t)k * (size_t)W * 3u * 64u + (size_t)lane) * R;
+
+        const unsigned char *rp = refl + 64 - lane;
+        int rcN = rp[0];
+        int eHN = edgeH[1];
+        int eDN = k == 0 ? DPX_NEG : (int)edgeD[1];
+#define DPX_AFF_STEP(MASKED_, HASROWS_)                                                                               \
+        {                                                                                                             \
+            const int rc = rcN, eH = eHN, eD = eDN;                                                                   \
+            rcN = rp[t + 1];                                                                                          \
+            eHN = edgeH[min(t + 2, n + 1)];                                                                           \
+            eDN = k == 0 ? DPX_NEG : (int)edgeD[min(t + 2, n + 1)];                                                   \
+            aff_step<R, STORE, MASKED_>(st, t, lane, n, HASROWS_, match, mismatch, oe, e, eH, eD, rc, edgeH, edgeD,   \
+                                        hasNext, tile + (size_t)t * 192u * R);                                        \
+        }
+        const bool fast = (base + 64 * R <= m) && (n >= 64);
+        if (fast) {
+            int t = 0;
+            for (; t < 63; t++) DPX_AFF_STEP(true, true)
+            for (; t < n; t++) DPX_AFF_STEP(false, true)
+            for (; t < W; t++) DPX_AFF_STEP(true, true)
+        } else {
+            for (int t = 0; t < W; t++) DPX_AFF_STEP(true, laneHasRows)
+        }
+#undef DPX_AFF_STEP
+    }
+    const int lastBase = (S - 1) * 64 * R;
+    const int lm = (m - 1 - lastBase) / R, rm = (m - 1 - lastBase) % R;
+    if (lane == lm) {
+        int v = st.Hl[0];
+#pragma unroll
+        for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+        a.score[p] = v; /* scoringMemo[m][n] (:365) */
+        a.endRow[p] = m;
+        a.endCol[p] = n;
+    }
+}
+
+/* =====================================================================================================
+ * Export: un-tile one pair's plane into the reference's row-major (m+1) x (n+1) layout, borders included.
+ * ===================================================================================================== */
+__global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, int R, int planes, int plane, int gapOpen,
+                                int gapExtend, int band, int16_t *out) {
+    const int n = pr.n, m = pr.m;
+    const size_t total = (size_t)(m + 1) * (size_t)(n + 1);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / (size_t)(n + 1));
+        const int j = (int)(idx % (size_t)(n + 1));
+        int v;
+        if (i == 0 || j == 0) {
+            const int len = i + j; /* one of them is 0 */
+            if (plane != 0) v = 0;                                   /* I / D are zero-initialised (ANW.cpp:24-27) */
+            else if (algo == DPX_K_LNW) v = len * gapOpen;           /* LNW.cpp:31-41 */
+            else if (algo == DPX_K_ANW) v = len == 0 ? 0 : gapOpen + len * gapExtend; /* ANW.cpp:43-53 */
+            else v = 0;                                              /* LSW / BSW */
+        } else if (algo == DPX_K_BSW) {
+            const int dlt = i - j;
+            v = (dlt <= band - 1 && -dlt <= band - 1) ? mat[pr.matOff + dpx_band_index(i, j, band)] : 0;
+        } else {
+            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, planes, plane)];
+        }
+        out[idx] = (int16_t)v;
+    }
+}
+
+/* =====================================================================================================
+ * DPX primitive probe (dpx_prim_eval): runs the CDNA4 mappings of dpx_prims.hpp on the device.
+ * ===================================================================================================== */
+__global__ void k_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
+                            uint32_t *res, uint32_t *pred) {
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= count) return;
+    const uint32_t A = a[x], B = b[x], C = c[x];
+    const int sa = (int)A, sb = (int)B, sc = (int)C;
+    bool p = false, ph = false, pl = false;
+    uint32_t r = 0;
+    switch (op[x]) {
+    case 0: r = (uint32_t)dpx::vimax3_s32(sa, sb, sc); break;
+    case 1: r = dpx::vimax3_s16x2(A, B, C); break;
+    case 2: r = dpx::vimax3_u32(A, B, C); break;
+    case 3: r = dpx::vimax3_u16x2(A, B, C); break;
+    case 4: r = (uint32_t)dpx::vimin3_s32(sa, sb, sc); break;
+    case 5: r = dpx::vimin3_s16x2(A, B, C); break;
+    case 6: r = dpx::vimin3_u32(A, B, C); break;
+    case 7: r = dpx::vimin3_u16x2(A, B, C); break;
+    case 8: r = (uint32_t)dpx::vimax_s32_relu(sa, sb); break;
+    case 9: r = dpx::vimax_s16x2_relu(A, B); break;
+    case 10: r = (uint32_t)dpx::vimin_s32_relu(sa, sb); break;
+    case 11: r = dpx::vimin_s16x2_relu(A, B); break;
+    case 12: r = (uint32_t)dpx::vimax3_s32_relu(sa, sb, sc); break;
+    case 13: r = dpx::vimax3_s16x2_relu(A, B, C); break;
+    case 14: r = (uint32_t)dpx::vimin3_s32_relu(sa, sb, sc); break;
+    case 15: r = dpx::vimin3_s16x2_relu(A, B, C); break;
+    case 16: r = (uint32_t)dpx::vibmax_s32(sa, sb, &p); break;
+    case 17: r = dpx::vibmax_u32(A, B, &p); break;
+    case 18: r = (uint32_t)dpx::vibmin_s32(sa, sb, &p); break;
+    case 19: r = dpx::vibmin_u32(A, B, &p); break;
+    case 20: r = dpx::vibmax_s16x2(A, B, &ph, &pl); break;
+    case 21: r = dpx::vibmax_u16x2(A, B, &ph, &pl); break;
+    case 22: r = dpx::vibmin_s16x2(A, B, &ph, &pl); break;
+    case 23: r = dpx::vibmin_u16x2(A, B, &ph, &pl); break;
+    case 24: r = (uint32_t)dpx::viaddmax_s32(sa, sb, sc); break;
+    case 25: r = dpx::viaddmax_u32(A, B, C); break;
+    case 26: r = dpx::viaddmax_s16x2(A, B, C); break;
+    case 27: r = dpx::viaddmax_u16x2(A, B, C); break;
+    case 28: r = (uint32_t)dpx::viaddmin_s32(sa, sb, sc); break;
+    case 29: r = dpx::viaddmin_u32(A, B, C); break;
+    case 30: r = dpx::viaddmin_s16x2(A, B, C); break;
+    case 31: r = dpx::viaddmin_u16x2(A, B, C); break;
+    case 32: r = (uint32_t)dpx::viaddmax_s32_relu(sa, sb, sc); break;
+    case 33: r = dpx::viaddmax_s16x2_relu(A, B, C); break;
+    case 34: r = (uint32_t)dpx::viaddmin_s32_relu(sa, sb, sc); break;
+    case 35: r = dpx::viaddmin_s16x2_relu(A, B, C); break;
+    default: break;
+    }
+    res[x] = r;
+    const int o = op[x];
+    pred[x] = (o >= 20 && o <= 23) ? (uint32_t)((ph ? 2 : 0) | (pl ? 1 : 0)) : (uint32_t)(p ? 1 : 0);
+}
+
+template <class K>
+hipError_t launch_fill_kernel(K kernel, const dpx_fill_args &a, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds > 64u * 1024u) { /* opt in to more than the default 64 KiB of dynamic LDS (160 KiB per CU on gfx950) */
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(DPX_FILL_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_linear_R(const dpx_fill_args &a, bool local, bool store, dim3 grid, size_t lds, hipStream_t s) {
+    if (local) return store ? launch_fill_kernel(k_linear_fill<R, true, true>, a, grid, lds, s)
+                            : launch_fill_kernel(k_linear_fill<R, true, false>, a, grid, lds, s);
+    return store ? launch_fill_kernel(k_linear_fill<R, false, true>, a, grid, lds, s)
+                 : launch_fill_kernel(k_linear_fill<R, false, false>, a, grid, lds, s);
+}
+
+template <int R>
+hipError_t launch_affine_R(const dpx_fill_args &a, bool store, dim3 grid, size_t lds, hipStream_t s) {
+    return store ? launch_fill_kernel(k_affine_fill<R, true>, a, grid, lds, s)
+                 : launch_fill_kernel(k_affine_fill<R, false>, a, grid, lds, s);
+}
+
+} // namespace
+
+/* ---- host-callable launchers (used by dpx_capi.cpp) ---- */
+
+hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
+    if (algo == DPX_K_LNW || algo == DPX_K_LSW) {
+        const bool local = algo == DPX_K_LSW;
+        switch (R) {
+        case 2: return launch_linear_R<2>(a, local, store, grid, ldsBytes, stream);
+        case 4: return launch_linear_R<4>(a, local, store, grid, ldsBytes, stream);
+        case 8: return launch_linear_R<8>(a, local, store, grid, ldsBytes, stream);
+        case 16: return launch_linear_R<16>(a, local, store, grid, ldsBytes, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (algo == DPX_K_ANW) {
+        switch (R) {
+        case 2: return launch_affine_R<2>(a, store, grid, ldsBytes, stream);
+        case 4: return launch_affine_R<4>(a, store, grid, ldsBytes, stream);
+        case 8: return launch_affine_R<8>(a, store, grid, ldsBytes, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
+                             int gapExtend, int band, int16_t *out, hipStream_t stream) {
+    const size_t total = (size_t)(pr.m + 1) * (size_t)(pr.n + 1);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(k_export_matrix, dim3(blocks), dim3(256), 0, stream, mat, pr, algo, R, planes, plane, gapOpen,
+                       gapExtend, band, out);
+    return hipGetLastError();
+}
+
+hipError_t dpx_launch_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
+                                uint32_t *res, uint32_t *pred, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prim_eval, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, op, a, b, c, count, res,
+                       pred);
+    return hipGetLastError();
+}

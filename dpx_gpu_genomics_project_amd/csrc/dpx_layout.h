@@ -1,0 +1,73 @@
+/*
+ * dpx_layout.h -- the engine's device-resident matrix layouts (shared by host and device code).
+ *
+ * Full-matrix algorithms (LNW / LSW / ANW): "wavefront-tiled" layout.
+ *   One wave owns a pair.  Query rows are cut into stripes of 64*R rows; lane l of the wave owns the R
+ *   consecutive rows [l*R, l*R+R) of the stripe and sweeps the columns with a skew of one column per lane
+ *   (lane l is on column t-l+1 at step t), so at any step the wave sits on one anti-diagonal of R-row tiles.
+ *   What a wave produces in one step is stored contiguously:
+ *
+ *       element(i, j, plane) = (((k*W + (j-1) + l) * P + plane) * 64 + l) * R + r
+ *       with i0 = i-1, k = i0 / (64R), l = (i0 % (64R)) / R, r = i0 % R, W = n + 63, P = planes (1, or 3 for ANW)
+ *
+ *   i.e. [stripe][step][plane][lane][row-in-lane] int16.  Every step of a wave is one fully coalesced
+ *   64*R*2-byte store per plane (1 KiB at R = 8).  The reference reached the same idea in
+ *   cuda/LNW/LinearNeedlemanWunschV17.cu:106-118 (skewed direction matrix, un-skewed by the back-tracker).
+ *   Border row 0 / column 0 are not stored (they are closed-form); dpx_batch_matrix() re-creates them.
+ *
+ * Banded SW: anti-diagonal-major band layout, see dpx_band_index().
+ */
+#ifndef DPX_LAYOUT_H
+#define DPX_LAYOUT_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define DPX_HD __host__ __device__ __forceinline__
+#else
+#define DPX_HD static inline
+#endif
+
+#define DPX_WAVE 64
+#define DPX_NEG (-(1 << 29)) /* "minus infinity" for the affine gap matrices' virtual borders */
+
+/* per-pair record the kernels read (device copy of dpx_seq_pair + placement) */
+typedef struct dpx_pair_dev {
+    int32_t refIdx, n;  /* reference offset / length  (columns) */
+    int32_t qryIdx, m;  /* query offset / length      (rows)    */
+    uint64_t matOff;    /* first int16 element of this pair's matrix block */
+} dpx_pair_dev;
+
+/* number of stripes / elements of one pair's block */
+DPX_HD int dpx_tiled_stripes(int m, int R) { return (m + 64 * R - 1) / (64 * R); }
+DPX_HD uint64_t dpx_tiled_elems(int m, int n, int R, int planes) {
+    if (m <= 0 || n <= 0) return 0;
+    return (uint64_t)dpx_tiled_stripes(m, R) * (uint64_t)(n + 63) * (uint64_t)planes * 64u * (uint64_t)R;
+}
+DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int planes, int plane) {
+    int i0 = i - 1;
+    int k = i0 / (64 * R);
+    int l = (i0 % (64 * R)) / R;
+    int r = i0 % R;
+    uint64_t T = (uint64_t)k * (uint64_t)(n + 63) + (uint64_t)(j - 1) + (uint64_t)l;
+    return ((T * (uint64_t)planes + (uint64_t)plane) * 64u + (uint64_t)l) * (uint64_t)R + (uint64_t)r;
+}
+
+/*
+ * Banded SW (band B: cells with |i-j| <= B-1).  The wave walks anti-diagonals a = i + j (2 .. m+n).
+ * On one anti-diagonal the in-band cells have u = i - j + (B-1) in [0, 2B-2] with u == (a + B - 1) mod 2,
+ * so there are at most B of them: slot s = u >> 1 in [0, B).  Storage is [a-2][slot] int16, slots padded to
+ * SP = 64*C (C = cells per lane); lane l holds slots [l*C, l*C+C).
+ */
+DPX_HD int dpx_band_cpl(int band) { return (band + 63) / 64; }            /* cells per lane */
+DPX_HD uint64_t dpx_band_elems(int m, int n, int band) {
+    if (m <= 0 || n <= 0) return 0;
+    return (uint64_t)(m + n - 1) * 64u * (uint64_t)dpx_band_cpl(band);
+}
+DPX_HD uint64_t dpx_band_index(int i, int j, int band) {
+    int a = i + j;
+    int u = i - j + (band - 1);
+    return (uint64_t)(a - 2) * 64u * (uint64_t)dpx_band_cpl(band) + (uint64_t)(u >> 1);
+}
+
+#endif
