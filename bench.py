@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X pairwise-alignment DP engine.
+
+Metric (BASELINE.json): GCUPS = sum(refLen*queryLen) / seconds / 1e9 (the reference's own formula,
+cuda/LNW/LinearNeedlemanWunschV12.cu:487-491) on a 10k-pair 1024x1024 LinearSmithWaterman batch PER GPU
+(weak scaling: every rank owns an independent 10k-pair sub-batch; the only collective is one RCCL gather of
+the int32 scores to rank 0 per step).  A "step" = one DP fill of the whole resident batch, int16 score matrix
+written to HBM, + that gather.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     algorithmic HBM bytes per fill / mean fill-kernel time (HIP events on the launch stream)
+  "cpu_baseline": the reference's own CPU classes (oracle/_ref, built from /root/reference in the build
+                  container) or, if that binary is absent, the C oracle port -- timed on this host's cores on a
+                  bounded sample of the same batch.  Reported beside the GPU number, never measured as it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+WORKLOADS = {
+    # name: (algo, pairs/GPU, m, n, match, mismatch, gapOpen, gapExtend, seed)
+    "lsw_10k_1024": ("LSW", 10000, 1024, 1024, 3, -1, -2, -1, 1),
+    "lsw_1k_512": ("LSW", 1000, 512, 512, 3, -1, -2, -1, 2),
+    "anw_1k_1024": ("ANW", 1000, 1024, 1024, 3, -1, -3, -1, 3),
+    "lnw_10k_1024": ("LNW", 10000, 1024, 1024, 3, -1, -2, -1, 7),
+}
+
+
+class _DevArray:
+    """Zero-copy view of engine-owned device memory for torch (RCCL gather source)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pairs):
+    """Time the reference CPU path on a bounded sample (first `budget_pairs` pairs of this rank's batch)."""
+    import numpy as np
+    from dpx_gpu_genomics_project_amd.synth import SynthBatch, write_pairs_file
+
+    cores = os.cpu_count() or 1
+    npairs = min(budget_pairs, sb.num_pairs)
+    end = int(sb.pairs["queryIdx"][npairs - 1] + sb.pairs["querySize"][npairs - 1] + 1)
+    sample = SynthBatch(sb.sequences[:end], sb.pairs[:npairs], sb.m, sb.n)
+    ref_o2 = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
+    ref_o0 = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    desc = f"first {npairs} pairs of the rank-0 batch ({sb.m}x{sb.n}), fill = init_matrix+score_matrix"
+    if os.path.exists(ref_o2) and algo_name in ("LSW", "LNW", "ANW"):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.txt")
+            write_pairs_file(sample, path)
+            args = [algo_name, path, str(match), str(mismatch), str(gap_open), str(gap_extend)]
+            o2 = json.loads(subprocess.run([ref_o2, "time"] + args + [str(npairs)], capture_output=True, text=True, check=True).stdout)
+            out = {"value": round(o2["fill_gcups"], 4), "unit": "GCUPS", "cores": cores, "kind": "reference",
+                   "sample": desc + "; reference classes built -O2, 20 pthreads x 20 pairs per batch (c++/main.cpp:18-19)",
+                   "threads": 20, "align_gcups_O2": round(o2["align_gcups"], 4)}
+            if os.path.exists(ref_o0):  # the reference's own flags (c++/Makefile:2), on a tenth of the sample
+                n0 = max(npairs // 10, 1)
+                o0 = json.loads(subprocess.run([ref_o0, "time"] + args + [str(n0)], capture_output=True, text=True, check=True).stdout)
+                out["fill_gcups_O0"] = round(o0["fill_gcups"], 4)
+                out["align_gcups_O0"] = round(o0["align_gcups"], 4)
+            return out
+    # fallback baseline: the C oracle port (still only a baseline -- never the measured product)
+    import ctypes as C
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.orc_fill_batch_timed.restype = C.c_double
+    lib.orc_fill_batch_timed.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 6 + [C.c_void_p]
+    scores = np.zeros(npairs, np.int32)
+    code = {"LNW": 0, "LSW": 1, "ANW": 2, "BSW": 3}[algo_name]
+    pairs = np.ascontiguousarray(sample.pairs)
+    sec = lib.orc_fill_batch_timed(code, sample.sequences.ctypes.data, pairs.ctypes.data, npairs, match, mismatch, gap_open,
+                                   gap_extend, 128, cores, scores.ctypes.data)
+    return {"value": round(sample.cells / sec / 1e9, 4), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": desc + f"; C oracle (gcc -O2), {cores} pthreads", "threads": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="lsw_10k_1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=4000, help="pairs of the CPU-baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import dpx_gpu_genomics_project_amd as dpx
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dpx.init(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    algo_name, npairs, m, n, match, mismatch, gap_open, gap_extend, seed = WORKLOADS[args.workload]
+    if args.pairs:
+        npairs = args.pairs
+    algo = {"LNW": dpx.ALGO_LNW, "LSW": dpx.ALGO_LSW, "ANW": dpx.ALGO_ANW}[algo_name]
+    # independent sub-batch per rank (weak scaling): same composition, different seed / pair indices
+    sb = dpx.make_batch(npairs, m, n, seed=seed + 1000 * rank, first_index=rank * npairs)
+    batch = dpx.Batch(algo, sb.sequences, sb.pairs, match, mismatch, gap_open, gap_extend)
+    info = batch.info()
+    stream = torch.cuda.current_stream().cuda_stream
+    d_scores, _, _ = batch.device_results()
+    scores_t = torch.as_tensor(_DevArray(d_scores, npairs), device=torch.device("cuda", local_rank))
+    gathered = [torch.empty(npairs, dtype=torch.int32, device=scores_t.device) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        batch.fill(stream)  # async launch on torch's current stream
+        if world > 1:
+            dist.gather(scores_t, gathered, dst=0)  # RCCL over xGMI: 4 B x pairs per rank
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        batch.fill(stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.gather(scores_t, gathered, dst=0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=scores_t.device)
+    kt = torch.tensor([kernel_ms], dtype=torch.float64, device=scores_t.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t.item()), float(kt.item())
+
+    # sanity on results (outside the timed region): a few pairs against the closed-form identical-pair score
+    scores, er, ec = batch.results()
+    ident = [p for p in range(npairs) if (rank * npairs + p) % 101 == 100][:4]
+    for p in ident:
+        assert scores[p] == match * min(m, n), "identical pair must score match*len"
+
+    if rank == 0:
+        total_cells = info["cells"] * world
+        value = total_cells * args.steps / elapsed / 1e9
+        achieved = info["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(args.workload)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{algo_name} {npairs}-pair {m}x{n} batch per GPU, int16 score matrix written to HBM",
+                       "algorithm": algo_name, "pairs_per_gpu": npairs, "query_len": m, "reference_len": n,
+                       "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
+                       "parallelism": f"{world} rank(s), 1 per GPU, pairs sharded, RCCL gather of int32 scores" if world > 1 else "1 GPU",
+                       "cells_per_gpu": info["cells"], "matrix_bytes_per_gpu": info["matrix_bytes"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
+                         "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, args.cpu_pairs)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
