@@ -65,7 +65,7 @@ def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pa
             write_pairs_file(sample, path)
             args = [algo_name, path, str(match), str(mismatch), str(gap_open), str(gap_extend)]
             o2 = json.loads(subprocess.run([ref_o2, "time"] + args + [str(npairs)], capture_output=True, text=True, check=True).stdout)
-            out = {"value": round(o2["fill_gcups"], 4), "unit": "GCUPS", "cores": cores, "kind": "reference",
+            out = {"value": round(o2["fill_gcups"], 4), "unit": "GCUPS", "cores": min(20, cores), "host_cores": cores, "kind": "reference",
                    "sample": desc + "; reference classes built -O2, 20 pthreads x 20 pairs per batch (c++/main.cpp:18-19)",
                    "threads": 20, "align_gcups_O2": round(o2["align_gcups"], 4)}
             if os.path.exists(ref_o0):  # the reference's own flags (c++/Makefile:2), on a tenth of the sample
@@ -130,7 +130,12 @@ def main():
     sb = dpx.make_batch(npairs, m, n, seed=seed + 1000 * rank, first_index=rank * npairs)
     batch = dpx.Batch(algo, sb.sequences, sb.pairs, match, mismatch, gap_open, gap_extend)
     info = batch.info()
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated (non-null) torch stream is made current: the fill kernel, the HIP events that time it and the
+    # RCCL gather are all ordered on it
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "expected a non-null HIP stream handle"
     d_scores, _, _ = batch.device_results()
     scores_t = torch.as_tensor(_DevArray(d_scores, npairs), device=torch.device("cuda", local_rank))
     gathered = [torch.empty(npairs, dtype=torch.int32, device=scores_t.device) for _ in range(world)] if (world > 1 and rank == 0) else None

@@ -66,7 +66,8 @@ struct dpx_batch {
     int32_t *dOrder = nullptr;
     int16_t *dMat = nullptr;
     int32_t *dScore = nullptr, *dEndRow = nullptr, *dEndCol = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     /* the batch's own stream */
+    hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
     size_t ldsBytes = 0;
 };
@@ -288,6 +289,7 @@ int dpx_batch_fill(dpx_batch *b, void *stream) {
     if (rc != DPX_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
     HIP_TRY(dpx_launch_fill(b->args, b->prm.algo, b->R, b->store, b->ldsBytes, s));
+    b->lastStream = s;
     b->filled = true;
     return DPX_OK;
 }
@@ -311,6 +313,7 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *usecPerFill = (double)ms * 1000.0 / repeats;
+    b->lastStream = b->stream;
     b->filled = true;
     return DPX_OK;
 }
@@ -319,6 +322,7 @@ int dpx_batch_sync(dpx_batch *b) {
     if (!b) return DPX_ERR_INVALID;
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
+    if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DPX_OK;
 }
@@ -336,6 +340,7 @@ int dpx_batch_results(dpx_batch *b, int32_t *scores, int32_t *endRow, int32_t *e
     if (!b->filled) return DPX_ERR_NOT_FILLED;
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
+    if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     const size_t bytes = b->numPairs * sizeof(int32_t);
     if (bytes) {
@@ -355,6 +360,7 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     const dpx_pair_dev &pd = b->pairs[pair];
     const size_t total = (size_t)(pd.m + 1) * (size_t)(pd.n + 1);
     int16_t *dOut = nullptr;
+    if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipMalloc((void **)&dOut, total * sizeof(int16_t)));
     hipError_t e = dpx_launch_export(b->dMat, pd, b->prm.algo, b->R, b->planes, which, b->prm.gapOpen, b->prm.gapExtend,
                                      b->prm.band, dOut, b->stream);
