@@ -138,12 +138,12 @@ def main():
     assert stream, "expected a non-null HIP stream handle"
     d_scores, _, _ = batch.device_results()
     scores_t = torch.as_tensor(_DevArray(d_scores, npairs), device=torch.device("cuda", local_rank))
-    gathered = [torch.empty(npairs, dtype=torch.int32, device=scores_t.device) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from dpx_gpu_genomics_project_amd.shard import gather_scores
 
     def step():
         batch.fill(stream)  # async launch on torch's current stream
         if world > 1:
-            dist.gather(scores_t, gathered, dst=0)  # RCCL over xGMI: 4 B x pairs per rank
+            return gather_scores(scores_t, rank, world)  # RCCL over xGMI: 4 B x pairs per rank
 
     def fence():
         if world > 1:
@@ -160,7 +160,7 @@ def main():
         batch.fill(stream)
         ev[k][1].record()
         if world > 1:
-            dist.gather(scores_t, gathered, dst=0)
+            gather_scores(scores_t, rank, world)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
