@@ -54,11 +54,12 @@ struct dpx_batch {
     dpx_params prm{};
     unsigned flags = 0;
     size_t numPairs = 0;
-    int R = 8;
+    int R = 8;          /* rows per lane (full-matrix kernels) or cells per lane (band kernel) */
+    int kernelAlgo = 0; /* algorithm the kernel runs (BSW with a covering band runs as LSW) */
     int planes = 1;
     bool store = true;
     bool filled = false;
-    uint64_t cells = 0, matElems = 0, algBytes = 0;
+    uint64_t cells = 0, matElems = 0, algBytes = 0, bandCells = 0;
     int maxN = 0, maxM = 0;
     std::vector<dpx_pair_dev> pairs; /* host mirror of the device pair table */
     char *dSeq = nullptr;
@@ -151,7 +152,7 @@ static bool fits_int16(const dpx_params &p, long long m, long long n) {
     if (p.algo == DPX_ALGO_LSW || p.algo == DPX_ALGO_BSW) {
         /* 0 <= H <= max(match,0) * min(m,n); the kernel also packs the column into 16 bits */
         long long top = std::max<long long>(p.match, 0) * std::min(m, n);
-        return top <= lim && n <= 65000;
+        return top <= lim && n <= 65000 && (m + n) <= 65000;
     }
     long long w = std::max({ab(p.match), ab(p.mismatch), ab(p.gapOpen)});
     if (p.algo == DPX_ALGO_LNW) return (m + n) * w <= lim;
@@ -220,16 +221,40 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (v == 2 || v == 4 || v == 8 || (v == 16 && params->algo != DPX_ALGO_ANW)) R = v;
     }
     b->R = R;
-    if (params->algo == DPX_ALGO_BSW) { delete b; return DPX_ERR_UNSUPPORTED; } /* banded kernel: next milestone */
+    int kernelAlgo = params->algo;
+    if (params->algo == DPX_ALGO_BSW) {
+        if (params->band >= std::max(b->maxM, b->maxN)) {
+            kernelAlgo = DPX_ALGO_LSW; /* the band covers every cell: identical to the unbanded recurrence */
+        } else if (params->band > 512) {
+            delete b;
+            return DPX_ERR_UNSUPPORTED; /* band kernel holds <= 8 cells per lane (band <= 512) */
+        } else {
+            b->R = dpx_band_cpl(params->band);
+        }
+    }
+    b->kernelAlgo = kernelAlgo;
+    const bool banded = kernelAlgo == DPX_ALGO_BSW;
 
     /* matrix placement + algorithmic bytes: int16 cells incl. borders, sequences, 16 B pair record, 12 B result */
     uint64_t off = 0;
     for (size_t i = 0; i < numPairs; i++) {
         dpx_pair_dev &pd = b->pairs[i];
         pd.matOff = off;
-        if (b->store) off += dpx_tiled_elems(pd.m, pd.n, R, b->planes);
+        if (b->store) off += banded ? dpx_band_elems(pd.m, pd.n, params->band) : dpx_tiled_elems(pd.m, pd.n, b->R, b->planes);
         b->algBytes += (uint64_t)pd.m + (uint64_t)pd.n + 16u + 12u;
-        if (b->store) b->algBytes += 2ull * (uint64_t)b->planes * (uint64_t)(pd.m + 1) * (uint64_t)(pd.n + 1);
+        if (b->store) {
+            if (banded) { /* 2 B per in-band cell */
+                uint64_t inband = 0;
+                for (int i = 1; i <= pd.m; i++) {
+                    const int lo = std::max(1, i - params->band + 1), hi = std::min(pd.n, i + params->band - 1);
+                    if (hi >= lo) inband += (uint64_t)(hi - lo + 1);
+                }
+                b->bandCells += inband;
+                b->algBytes += 2ull * inband;
+            } else {
+                b->algBytes += 2ull * (uint64_t)b->planes * (uint64_t)(pd.m + 1) * (uint64_t)(pd.n + 1);
+            }
+        }
     }
     b->matElems = off;
 
@@ -237,7 +262,8 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const size_t edgeBytes = align_up((size_t)(b->maxN + 2) * 2, 16);
     const size_t nEdges = params->algo == DPX_ALGO_ANW ? 2 : 1;
     const size_t refBytes = align_up((size_t)b->maxN + 128, 16);
-    const size_t perWave = edgeBytes * nEdges + refBytes;
+    const size_t qBytes = align_up((size_t)b->maxM + 16, 16);
+    const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 
@@ -278,7 +304,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     a.score = b->dScore; a.endRow = b->dEndRow; a.endCol = b->dEndCol;
     a.ldsPerWave = (uint32_t)perWave;
     a.ldsEdge2Off = (uint32_t)edgeBytes;
-    a.ldsRefOff = (uint32_t)(edgeBytes * nEdges);
+    a.ldsRefOff = banded ? (uint32_t)qBytes : (uint32_t)(edgeBytes * nEdges);
     *out = b;
     return DPX_OK;
 }
@@ -288,7 +314,7 @@ int dpx_batch_fill(dpx_batch *b, void *stream) {
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    HIP_TRY(dpx_launch_fill(b->args, b->prm.algo, b->R, b->store, b->ldsBytes, s));
+    HIP_TRY(dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s));
     b->lastStream = s;
     b->filled = true;
     return DPX_OK;
@@ -303,7 +329,7 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, b->stream));
     for (int i = 0; i < repeats; i++) {
-        hipError_t e = dpx_launch_fill(b->args, b->prm.algo, b->R, b->store, b->ldsBytes, b->stream);
+        hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, b->stream);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hip_fail(e, "dpx_launch_fill"); }
     }
     HIP_TRY(hipEventRecord(e1, b->stream));
@@ -362,7 +388,7 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     int16_t *dOut = nullptr;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipMalloc((void **)&dOut, total * sizeof(int16_t)));
-    hipError_t e = dpx_launch_export(b->dMat, pd, b->prm.algo, b->R, b->planes, which, b->prm.gapOpen, b->prm.gapExtend,
+    hipError_t e = dpx_launch_export(b->dMat, pd, b->kernelAlgo, b->R, b->planes, which, b->prm.gapOpen, b->prm.gapExtend,
                                      b->prm.band, dOut, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dOut, total * sizeof(int16_t), hipMemcpyDeviceToHost);

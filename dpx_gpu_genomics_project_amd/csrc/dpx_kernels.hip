@@ -369,6 +369,158 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
 }
 
 /* =====================================================================================================
+ * Banded Smith-Waterman (python/LinearBandedSmithWaterman.py:62-104): the LSW recurrence restricted to
+ * |i-j| <= B-1; every cell outside the band (and the borders) reads as 0.
+ *
+ * The band is walked by anti-diagonals a = i+j.  One anti-diagonal holds at most B in-band cells
+ * (slot s = (i-j+B-1)>>1); lane l owns the C = ceil(B/64) slots [l*C, l*C+C), so all 64 lanes work on every
+ * step -- no stripes, no skew, no LDS edge row.  With p = (a+B-1)&1 the neighbours on the previous
+ * anti-diagonal are   p=1: up = prev[s], left = prev[s+1]      p=0: up = prev[s-1], left = prev[s]
+ * and the diagonal is prev2[s]; the one value that crosses a lane boundary moves with a single DPP
+ * (wave_shl:1 / wave_shr:1).  Query / reference characters ride along in registers: entering a p=1 step the
+ * query window slides one slot down, entering a p=0 step the reference window slides one slot up.
+ * ===================================================================================================== */
+template <int C>
+struct BandState {
+    int prev[C], prev2[C]; /* anti-diagonals a-1 and a-2 */
+    int qch[C], rch[C];    /* query / reference character of each slot's cell */
+    unsigned key[C];       /* running max of (H << 16 | 0xFFFF - A): max score, then earliest step */
+};
+
+template <int C, bool P1>
+__device__ __forceinline__ void band_step(BandState<C> &st, const int A, const int lane, const int m, const int n, const int B,
+                                          const int match, const int mismatch, const int gap, const unsigned char *qL,
+                                          const unsigned char *rL, int *out) {
+    const int a = A + 2;
+    const int p = P1 ? 1 : 0;
+    const int i0 = (a + p - (B - 1)) >> 1; /* row of slot 0 (may be <= 0); a+p-(B-1) is even */
+    const int j0 = a - i0;                  /* column of slot 0 */
+    const int smin = max(max(1 - i0, j0 - n), 0);
+    const int smax = min(min(m - i0, j0 - 1), B - 1 - p);
+    int up[C], left[C];
+    if constexpr (P1) {
+        const int newq = qL[min(max(i0 + 64 * C - 2, 0), m - 1)];
+        const int tq = wave_shl1(st.qch[0], newq);
+#pragma unroll
+        for (int c = 0; c < C - 1; c++) st.qch[c] = st.qch[c + 1];
+        st.qch[C - 1] = tq;
+        const int nb = wave_shl1(st.prev[0], 0);
+#pragma unroll
+        for (int c = 0; c < C; c++) { up[c] = st.prev[c]; left[c] = (c < C - 1) ? st.prev[c + 1] : nb; }
+    } else {
+        const int newr = rL[min(max(j0 - 1, 0), n - 1)];
+        const int tr = wave_shr1(st.rch[C - 1], newr);
+#pragma unroll
+        for (int c = C - 1; c > 0; c--) st.rch[c] = st.rch[c - 1];
+        st.rch[0] = tr;
+        const int nb = wave_shr1(st.prev[C - 1], 0);
+#pragma unroll
+        for (int c = 0; c < C; c++) { left[c] = st.prev[c]; up[c] = (c > 0) ? st.prev[c - 1] : nb; }
+    }
+    const unsigned negA = 0xFFFFu - (unsigned)A;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int s = lane * C + c;
+        const bool valid = (s >= smin) && (s <= smax);
+        const int sc = (st.qch[c] == st.rch[c]) ? match : mismatch;
+        int h = max(max(max(up[c], left[c]) + gap, st.prev2[c] + sc), 0);
+        h = valid ? h : 0;
+        st.key[c] = max(st.key[c], ((unsigned)h << 16) | negA);
+        st.prev2[c] = st.prev[c];
+        st.prev[c] = h;
+        out[c] = h;
+    }
+}
+
+template <int C, bool PB, bool STORE>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int G = (C >= 8) ? 1 : 8 / C; /* steps per 16-byte store */
+    constexpr int GG = (G < 2) ? 2 : G;     /* steps per loop iteration (parity pattern repeats every 2) */
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    if (p >= a.numPairs) return;
+    if (a.order) p = a.order[p];
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m, B = a.band;
+    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    if (m <= 0 || n <= 0) {
+        if (lane == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
+        return;
+    }
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
+    unsigned char *qL = my;
+    unsigned char *rL = my + a.ldsRefOff;
+    for (int x = lane; x < m; x += 64) qL[x] = qry[x];
+    for (int x = lane; x < n; x += 64) rL[x] = ref[x];
+
+    BandState<C> st;
+    { /* character windows of the virtual anti-diagonal a = 1 (the first real step then slides one of them) */
+        const int p1 = B & 1; /* (1 + B - 1) & 1 */
+        const int i0 = (1 + p1 - (B - 1)) >> 1;
+        const int j0 = 1 - i0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int s = lane * C + c;
+            st.qch[c] = qL[min(max(i0 + s - 1, 0), m - 1)];
+            st.rch[c] = rL[min(max(j0 - s - 1, 0), n - 1)];
+            st.prev[c] = 0;
+            st.prev2[c] = 0;
+            st.key[c] = 0u;
+        }
+    }
+    const int NS = m + n - 1;               /* anti-diagonals a = 2 .. m+n */
+    const int numGroups = (NS + G - 1) / G;
+    int16_t *Hp = a.mat + pr.matOff + (size_t)lane * 8u;
+    int acc[8];
+    for (int A0 = 0; A0 < NS; A0 += GG) {
+        /* parity of step A is (A + B + 1) & 1; A0 is even, so even steps have parity PB and odd steps !PB */
+#pragma unroll
+        for (int g = 0; g < GG; g += 2) {
+            band_step<C, PB>(st, A0 + g, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);
+            if constexpr (STORE && G == 1) {
+                if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * 512u, acc);
+            }
+            band_step<C, !PB>(st, A0 + g + 1, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[((g + 1) % G) * C]);
+            if constexpr (STORE) {
+                if (((g + 1) % G) == G - 1) {
+                    const int grp = (A0 + g + 1) / G;
+                    if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * 512u, acc);
+                }
+            }
+        }
+    }
+    /* candidates: every slot's first maximum; rows/cols recovered from (step, slot).  Within a slot cells arrive in
+     * row-major order, so the earliest step is the slot's first maximum; across slots pick max score, min row, min col */
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int hv = (int)(st.key[c] >> 16);
+        if (hv > 0) {
+            const int A = 0xFFFF - (int)(st.key[c] & 0xFFFFu);
+            const int aa = A + 2;
+            const int pp = (aa + B - 1) & 1;
+            const int u = 2 * (lane * C + c) + pp;
+            const int i = (aa + u - (B - 1)) >> 1;
+            const int j = aa - i;
+            const unsigned long long k = ((unsigned long long)(unsigned)hv << 40) | ((unsigned long long)(0xFFFFFu - (unsigned)i) << 20) |
+                                         (unsigned long long)(0xFFFFFu - (unsigned)j);
+            mine = k > mine ? k : mine;
+        }
+    }
+    const unsigned long long top = wave_max_u64(mine);
+    if (lane == 0) {
+        const int hv = (int)(top >> 40);
+        a.score[p] = hv;
+        a.endRow[p] = hv > 0 ? (int)(0xFFFFFu - (unsigned)((top >> 20) & 0xFFFFFu)) : 0;
+        a.endCol[p] = hv > 0 ? (int)(0xFFFFFu - (unsigned)(top & 0xFFFFFu)) : 0;
+    }
+}
+
+/* =====================================================================================================
  * Export: un-tile one pair's plane into the reference's row-major (m+1) x (n+1) layout, borders included.
  * ===================================================================================================== */
 __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, int R, int planes, int plane, int gapOpen,
@@ -468,6 +620,15 @@ hipError_t launch_linear_R(const dpx_fill_args &a, bool local, bool store, dim3 
                  : launch_fill_kernel(k_linear_fill<R, false, false>, a, grid, lds, s);
 }
 
+template <int C>
+hipError_t launch_banded_C(const dpx_fill_args &a, bool store, dim3 grid, size_t lds, hipStream_t s) {
+    const bool pb = ((a.band + 1) & 1) != 0; /* parity of step A = 0 */
+    if (pb) return store ? launch_fill_kernel(k_banded_fill<C, true, true>, a, grid, lds, s)
+                         : launch_fill_kernel(k_banded_fill<C, true, false>, a, grid, lds, s);
+    return store ? launch_fill_kernel(k_banded_fill<C, false, true>, a, grid, lds, s)
+                 : launch_fill_kernel(k_banded_fill<C, false, false>, a, grid, lds, s);
+}
+
 template <int R>
 hipError_t launch_affine_R(const dpx_fill_args &a, bool store, dim3 grid, size_t lds, hipStream_t s) {
     return store ? launch_fill_kernel(k_affine_fill<R, true>, a, grid, lds, s)
@@ -489,6 +650,15 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
         case 4: return launch_linear_R<4>(a, local, store, grid, ldsBytes, stream);
         case 8: return launch_linear_R<8>(a, local, store, grid, ldsBytes, stream);
         case 16: return launch_linear_R<16>(a, local, store, grid, ldsBytes, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (algo == DPX_K_BSW) { /* here R carries the cells-per-lane count C = dpx_band_cpl(band) */
+        switch (R) {
+        case 1: return launch_banded_C<1>(a, store, grid, ldsBytes, stream);
+        case 2: return launch_banded_C<2>(a, store, grid, ldsBytes, stream);
+        case 4: return launch_banded_C<4>(a, store, grid, ldsBytes, stream);
+        case 8: return launch_banded_C<8>(a, store, grid, ldsBytes, stream);
         default: return hipErrorInvalidValue;
         }
     }

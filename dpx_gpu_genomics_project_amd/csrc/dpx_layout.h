@@ -54,20 +54,27 @@ DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int planes, int plan
 }
 
 /*
- * Banded SW (band B: cells with |i-j| <= B-1).  The wave walks anti-diagonals a = i + j (2 .. m+n).
- * On one anti-diagonal the in-band cells have u = i - j + (B-1) in [0, 2B-2] with u == (a + B - 1) mod 2,
- * so there are at most B of them: slot s = u >> 1 in [0, B).  Storage is [a-2][slot] int16, slots padded to
- * SP = 64*C (C = cells per lane); lane l holds slots [l*C, l*C+C).
+ * Banded SW (band B: cells with |i-j| <= B-1).  The wave walks anti-diagonals a = i + j (2 .. m+n), step A = a-2.
+ * On one anti-diagonal the in-band cells have u = i - j + (B-1) in [0, 2B-2] with u == (a + B - 1) mod 2, so at
+ * most B of them exist: slot s = u >> 1 in [0, B).  Lane l holds the C = ceil(B/64) slots [l*C, l*C+C).
+ * G = max(1, 8/C) consecutive steps are packed so that every lane writes 16 contiguous bytes:
+ *
+ *       element(i, j) = ((A/G)*64 + l) * (G*C) + (A%G)*C + c,   A = i+j-2, s = (i-j+B-1)>>1, l = s/C, c = s%C
  */
-DPX_HD int dpx_band_cpl(int band) { return (band + 63) / 64; }            /* cells per lane */
+DPX_HD int dpx_band_cpl(int band) { int c = (band + 63) / 64; return c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8; } /* cells per lane */
+DPX_HD int dpx_band_group(int C) { return C >= 8 ? 1 : 8 / C; }                                                /* steps per 16-B store */
 DPX_HD uint64_t dpx_band_elems(int m, int n, int band) {
     if (m <= 0 || n <= 0) return 0;
-    return (uint64_t)(m + n - 1) * 64u * (uint64_t)dpx_band_cpl(band);
+    const int C = dpx_band_cpl(band), G = dpx_band_group(C);
+    const uint64_t groups = ((uint64_t)(m + n - 1) + (uint64_t)G - 1) / (uint64_t)G;
+    return groups * 64u * (uint64_t)(G * C);
 }
 DPX_HD uint64_t dpx_band_index(int i, int j, int band) {
-    int a = i + j;
-    int u = i - j + (band - 1);
-    return (uint64_t)(a - 2) * 64u * (uint64_t)dpx_band_cpl(band) + (uint64_t)(u >> 1);
+    const int C = dpx_band_cpl(band), G = dpx_band_group(C);
+    const int A = i + j - 2;
+    const int s = (i - j + (band - 1)) >> 1;
+    const int l = s / C, c = s % C;
+    return ((uint64_t)(A / G) * 64u + (uint64_t)l) * (uint64_t)(G * C) + (uint64_t)((A % G) * C + c);
 }
 
 #endif

@@ -27,3 +27,10 @@ if __name__ == "__main__":
     os.environ["DPX_R"] = "8"
     run(dpx.ALGO_LNW, npairs, 1024, 1024)
     run(dpx.ALGO_ANW, max(npairs // 4, 1), 1024, 1024, ext=-1, gap=-3)
+    if len(sys.argv) > 2:
+        nb = int(sys.argv[2])
+        sb = dpx.make_batch(nb, 4096, 4096, seed=4)
+        b = dpx.Batch(dpx.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=128)
+        b.fill_timed(1); us = b.fill_timed(3); info = b.info()
+        print(f"BSW band128 pairs={nb} 4096x4096: {us/1e3:.3f} ms  {info['cells']/us/1e3:.1f} GCUPS(full-matrix cells)  in-band {nb*1028224/us/1e3:.1f} GCUPS  {info['algorithmic_bytes']/us/1e3:.1f} GB/s alg", flush=True)
+        b.close()
