@@ -71,6 +71,14 @@ struct dpx_batch {
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
     size_t ldsBytes = 0;
+    /* traceback (lazy): device line buffers + host mirror */
+    uint64_t *dTbOff = nullptr;
+    char *dTb = nullptr;
+    int32_t *dTbLen = nullptr;
+    std::vector<uint64_t> tbOff;
+    std::vector<char> hTb;
+    std::vector<int32_t> hTbLen;
+    bool tbValid = false;
 };
 
 extern "C" {
@@ -171,6 +179,9 @@ int dpx_batch_destroy(dpx_batch *b) {
     (void)hipFree(b->dScore);
     (void)hipFree(b->dEndRow);
     (void)hipFree(b->dEndCol);
+    (void)hipFree(b->dTbOff);
+    (void)hipFree(b->dTb);
+    (void)hipFree(b->dTbLen);
     delete b;
     return DPX_OK;
 }
@@ -317,6 +328,7 @@ int dpx_batch_fill(dpx_batch *b, void *stream) {
     HIP_TRY(dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s));
     b->lastStream = s;
     b->filled = true;
+    b->tbValid = false;
     return DPX_OK;
 }
 
@@ -341,6 +353,7 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     *usecPerFill = (double)ms * 1000.0 / repeats;
     b->lastStream = b->stream;
     b->filled = true;
+    b->tbValid = false;
     return DPX_OK;
 }
 
@@ -397,9 +410,49 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     return DPX_OK;
 }
 
+/* Run the traceback kernel for every pair of the batch and mirror the lines on the host (once per fill). */
+static int run_traceback(dpx_batch *b) {
+    if (b->tbValid) return DPX_OK;
+    const size_t np = b->numPairs;
+    if (b->tbOff.empty()) {
+        b->tbOff.resize(np + 1);
+        uint64_t off = 0;
+        for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)(b->pairs[i].m + b->pairs[i].n + 1); }
+        b->tbOff[np] = off;
+        HIP_TRY(hipMalloc((void **)&b->dTbOff, (np + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void **)&b->dTb, std::max<uint64_t>(off, 16)));
+        HIP_TRY(hipMalloc((void **)&b->dTbLen, std::max<size_t>(np, 1) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        b->hTb.resize(off);
+        b->hTbLen.resize(np);
+    }
+    if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
+    HIP_TRY(dpx_launch_traceback(b->args, b->kernelAlgo, b->R, b->planes, b->dTbOff, b->dTb, b->dTbLen, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (np) {
+        HIP_TRY(hipMemcpy(b->hTb.data(), b->dTb, b->hTb.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b->hTbLen.data(), b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    b->tbValid = true;
+    return DPX_OK;
+}
+
 int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine, char *qryLine, int32_t *len) {
-    (void)b; (void)pair; (void)refLine; (void)relLine; (void)qryLine; (void)len;
-    return DPX_ERR_UNSUPPORTED; /* next milestone */
+    if (!b || pair >= b->numPairs) return DPX_ERR_INVALID;
+    if (!b->store) return DPX_ERR_NO_MATRIX;
+    if (!b->filled) return DPX_ERR_NOT_FILLED;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    rc = run_traceback(b);
+    if (rc != DPX_OK) return rc;
+    const int cap = b->pairs[pair].m + b->pairs[pair].n + 1;
+    const int k = b->hTbLen[pair];
+    const char *base = b->hTb.data() + b->tbOff[pair];
+    char *dst[3] = {refLine, relLine, qryLine};
+    for (int l = 0; l < 3; l++)
+        if (dst[l]) { memcpy(dst[l], base + (size_t)l * cap + (cap - k), (size_t)k); dst[l][k] = 0; }
+    if (len) *len = k;
+    return DPX_OK;
 }
 
 int dpx_batch_info(dpx_batch *b, size_t *numPairs, uint64_t *cells, uint64_t *matrixBytes, uint64_t *algorithmicBytes) {

@@ -548,6 +548,103 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
 }
 
 /* =====================================================================================================
+ * Device traceback (the reference's on-device backtracking(), cuda/LNW/
+ * LinearNeedlemanWunschV19.cu:26-110, and host back-trackers c++/backtrack.cpp:21-356).
+ * One lane per pair walks back from the end cell.  Directions are not stored: they are recomputed from the
+ * int16 score matrices with the reference's own tie rules (a >= b wins for the FIRST argument of __vibmax):
+ *   LSW (c++/LinearSmithWaterman.cpp:106-108): UPPER, then LEFT, then CORNER; stop when the next cell is 0 (:222)
+ *   LNW (c++/LinearNeedlemanWunsch.cpp:122-125): INSERTION if left >= max(up, diag), else DELETION if up >= diag
+ *   ANW (c++/AffineNeedlemanWunsch.cpp:185-233, :258-360): 3-state walk over H / I / D, GAP_OPEN wins ties
+ * The three lines (reference / relation / query) are written right-aligned into the pair's buffer.
+ * ===================================================================================================== */
+struct TbView {
+    const int16_t *mat;
+    uint64_t off;
+    int n, m, R, planes, algo, band, gapOpen, gapExtend;
+    __device__ __forceinline__ int get(int i, int j, int plane) const {
+        if (i == 0 || j == 0) { /* closed-form borders, as in k_export_matrix */
+            const int len = i + j;
+            if (plane != 0) return 0;
+            if (algo == DPX_K_LNW) return len * gapOpen;
+            if (algo == DPX_K_ANW) return len == 0 ? 0 : gapOpen + len * gapExtend;
+            return 0;
+        }
+        if (algo == DPX_K_BSW) {
+            const int dlt = i - j;
+            if (dlt > band - 1 || -dlt > band - 1) return 0;
+            return mat[off + dpx_band_index(i, j, band)];
+        }
+        return mat[off + dpx_tiled_index(i, j, n, R, planes, plane)];
+    }
+};
+
+__global__ void k_traceback(const dpx_fill_args a, int algo, int R, int planes, const int32_t *endRow, const int32_t *endCol,
+                            const uint64_t *tbOff, char *tb, int32_t *tbLen) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.numPairs) return;
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m;
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    const int cap = m + n + 1;
+    char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
+    int pos = cap; /* lines grow from the back */
+    const int match = a.match, mismatch = a.mismatch;
+    TbView v{a.mat, pr.matOff, n, m, R, planes, algo, a.band, a.gapOpen, a.gapExtend};
+#define EMIT(rc_, xc_, qc_) { --pos; lr[pos] = (char)(rc_); lx[pos] = (char)(xc_); lq[pos] = (char)(qc_); }
+    int i = endRow[p], j = endCol[p];
+    if (algo == DPX_K_LSW || algo == DPX_K_BSW) {
+        const int g = a.gapOpen;
+        int h = (i > 0 && j > 0) ? v.get(i, j, 0) : 0;
+        while (h > 0) {
+            const int up = v.get(i - 1, j, 0), left = v.get(i, j - 1, 0), dg = v.get(i - 1, j - 1, 0);
+            if (up + g == h) { EMIT('_', ' ', qry[i - 1]); i--; h = up; }
+            else if (left + g == h) { EMIT(ref[j - 1], ' ', '_'); j--; h = left; }
+            else { EMIT(ref[j - 1], qry[i - 1] == ref[j - 1] ? '*' : '|', qry[i - 1]); i--; j--; h = dg; }
+        }
+    } else if (algo == DPX_K_LNW) {
+        const int g = a.gapOpen;
+        while (i != 0 || j != 0) {
+            if (i == 0) { EMIT(ref[j - 1], ' ', '_'); j--; continue; }  /* row-0 border: QUERY_INSERTION */
+            if (j == 0) { EMIT('_', ' ', qry[i - 1]); i--; continue; }  /* column-0 border: QUERY_DELETION */
+            const bool eq = qry[i - 1] == ref[j - 1];
+            const int mm = v.get(i - 1, j - 1, 0) + (eq ? match : mismatch);
+            const int del = v.get(i - 1, j, 0) + g, ins = v.get(i, j - 1, 0) + g;
+            const int vmax = max(del, mm);
+            if (ins >= vmax) { EMIT(ref[j - 1], ' ', '_'); j--; }
+            else if (del >= mm) { EMIT('_', ' ', qry[i - 1]); i--; }
+            else { EMIT(ref[j - 1], eq ? '*' : '|', qry[i - 1]); i--; j--; }
+        }
+    } else { /* ANW */
+        const int o = a.gapOpen, e = a.gapExtend;
+        int cur = 0; /* 0 SCORING, 1 INSERTION, 2 DELETION */
+        while (i != 0 && j != 0) {
+            if (cur == 0) {
+                const bool eq = qry[i - 1] == ref[j - 1];
+                const int mm = v.get(i - 1, j - 1, 0) + (eq ? match : mismatch);
+                const int D = v.get(i, j, 2), I = v.get(i, j, 1);
+                const int vmax = max(D, mm);
+                if (I >= vmax) cur = 1;
+                else if (D >= mm) cur = 2;
+                else { EMIT(ref[j - 1], eq ? '*' : '|', qry[i - 1]); i--; j--; }
+            } else if (cur == 1) {
+                const bool open = (j == 1) || (v.get(i, j - 1, 0) + o + e >= v.get(i, j - 1, 1) + e);
+                if (open) cur = 0;
+                EMIT(ref[j - 1], ' ', '_'); j--;
+            } else {
+                const bool open = (i == 1) || (v.get(i - 1, j, 0) + o + e >= v.get(i - 1, j, 2) + e);
+                if (open) cur = 0;
+                EMIT('_', ' ', qry[i - 1]); i--;
+            }
+        }
+        while (i > 0) { EMIT('_', ' ', qry[i - 1]); i--; }
+        while (j > 0) { EMIT(ref[j - 1], ' ', '_'); j--; }
+    }
+#undef EMIT
+    tbLen[p] = cap - pos;
+}
+
+/* =====================================================================================================
  * DPX primitive probe (dpx_prim_eval): runs the CDNA4 mappings of dpx_prims.hpp on the device.
  * ===================================================================================================== */
 __global__ void k_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
@@ -680,6 +777,14 @@ hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int alg
     if (blocks > 4096u) blocks = 4096u;
     hipLaunchKernelGGL(k_export_matrix, dim3(blocks), dim3(256), 0, stream, mat, pr, algo, R, planes, plane, gapOpen,
                        gapExtend, band, out);
+    return hipGetLastError();
+}
+
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int algo, int R, int planes, const uint64_t *tbOff, char *tb,
+                                int32_t *tbLen, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)((a.numPairs + 63) / 64)), dim3(64), 0, stream, a, algo, R, planes, a.endRow,
+                       a.endCol, tbOff, tb, tbLen);
     return hipGetLastError();
 }
 

@@ -1,0 +1,72 @@
+"""GPU parity of the device traceback: the three printed lines per pair, against (a) the reference's own stdout
+held in tests/golden/short400_*.out.gz and (b) the oracle's traceback on seeded batches."""
+import gzip
+import json
+import os
+
+import pytest
+
+import oracle_py as O
+from dpx_gpu_genomics_project_amd.synth import from_strings, make_batch, parse_pairs_file
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CODE = {"LNW": 0, "LSW": 1, "ANW": 2}
+
+
+def _block(p, score, lines, algo):
+    """The block the reference prints for one pair (c++/LinearSmithWaterman.cpp:240-288, LNW.cpp:199-221)."""
+    if algo == "LSW" and score == 0:
+        return f"{p} | 0\n\n\n\n"
+    return f"{p} | {score}\n{lines[0]}\n{lines[1]}\n{lines[2]}\n"
+
+
+@pytest.mark.parametrize("algo,w", [("LSW", (3, -1, -2, -1)), ("LNW", (3, -1, -2, -1)), ("ANW", (3, -1, -3, -1))])
+def test_reference_stdout_short400_byte_identical(gpu, algo, w):
+    sb = parse_pairs_file(os.path.join(G, "short400.txt"))
+    want = gzip.open(os.path.join(G, f"short400_{algo}.out.gz"), "rb").read().decode("latin-1")
+    with gpu.Batch(CODE[algo], sb.sequences, sb.pairs, *w) as b:
+        b.fill()
+        sc, _, _ = b.results()
+        got = "".join(_block(p, int(sc[p]), b.traceback(p), algo) for p in range(sb.num_pairs))
+    assert got == want
+
+
+def test_golden_matrix_cases_lines(gpu):
+    cases = json.load(open(os.path.join(G, "matrices.json")))
+    for c in cases:
+        sb = from_strings([(c["ref"], c["qry"])])
+        w = c["w"] + ([-1] if len(c["w"]) == 3 else [])
+        with gpu.Batch(CODE[c["algo"]], sb.sequences, sb.pairs, *w) as b:
+            b.fill()
+            sc, _, _ = b.results()
+            assert sc[0] == c["score"]
+            assert list(b.traceback(0)) == c["lines"], (c["algo"], c["w"], len(c["qry"]), len(c["ref"]))
+
+
+@pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
+def test_traceback_vs_oracle_multi_stripe(gpu, algo, monkeypatch):
+    monkeypatch.setenv("DPX_R", "2")  # 128-row stripes: the walk crosses stripe and lane boundaries
+    sb = make_batch(6, 300, 280, seed=21, first_index=95)
+    w = (3, -1, -3, -1) if algo == "ANW" else (3, -1, -2, -1)
+    with gpu.Batch(CODE[algo], sb.sequences, sb.pairs, *w) as b:
+        b.fill()
+        for p in range(sb.num_pairs):
+            refs, qry = sb.ref(p), sb.qry(p)
+            if algo == "LSW":
+                o = O.lsw(refs, qry, *w[:3]); want = ("", "", "") if o.score == 0 else O.lsw_traceback(refs, qry, o)
+            elif algo == "LNW":
+                o = O.lnw(refs, qry, *w[:3]); want = O.lnw_traceback(refs, qry, o)
+            else:
+                o = O.anw(refs, qry, *w); want = O.anw_traceback(refs, qry, o)
+            assert b.traceback(p) == want, (algo, p)
+
+
+def test_banded_traceback_vs_oracle(gpu):
+    sb = make_batch(5, 200, 220, seed=33, first_index=98)
+    with gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=24) as b:
+        b.fill()
+        for p in range(sb.num_pairs):
+            o = O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, band=24)
+            want = ("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)
+            assert b.traceback(p) == want, p
