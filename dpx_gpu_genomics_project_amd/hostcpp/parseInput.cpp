@@ -1,0 +1,96 @@
+// parseInput.cpp -- single-pass loader with the reference's observable behaviour (c++/parseInput.cpp:9-142):
+// same buffer contents, same seqPair records, same statistics, same failure mode (message on stderr + exit(1)
+// for an unreadable file or a line count that is not a multiple of 3), same INPUT_CAP of 10^7 pairs.
+#include "parseInput.h"
+
+#include <cstring>
+
+namespace {
+const size_t kInputCap = 10000000; // reference: #define INPUT_CAP (parseInput.cpp:7)
+
+[[noreturn]] void die(const char *fmt, const char *arg) {
+    fprintf(stderr, fmt, arg);
+    exit(1);
+}
+} // namespace
+
+inputInfo parseInput(const char *pairFileName, seqPair *&sequenceIdxs, char *&sequences) {
+    FILE *f = fopen(pairFileName, "rb");
+    if (!f) die("Could not open file: %s\n", pairFileName);
+    if (fseek(f, 0, SEEK_END) != 0) die("Could not size file: %s\n", pairFileName);
+    const long fileSize = ftell(f);
+    if (fileSize < 0) die("Could not size file: %s\n", pairFileName);
+    rewind(f);
+    const size_t numBytes = (size_t)fileSize;
+    sequences = (char *)malloc(numBytes ? numBytes : 1);
+    if (!sequences) die("Out of memory reading: %s\n", pairFileName);
+    size_t got = 0;
+    while (got < numBytes) {
+        const size_t k = fread(sequences + got, 1, numBytes - got, f);
+        if (k == 0) die("Did not read all bytes of: %s\n", pairFileName);
+        got += k;
+    }
+    fclose(f);
+
+    size_t numLines = 0;
+    for (const char *p = sequences, *e = sequences + numBytes; (p = (const char *)memchr(p, '\n', (size_t)(e - p))) != nullptr; ++p) numLines++;
+    if (numLines % 3 != 0) die("Number of lines not a multiple of 3: %s\n", pairFileName);
+    size_t numPairs = numLines / 3;
+    sequenceIdxs = (seqPair *)malloc((numPairs ? numPairs : 1) * sizeof(seqPair));
+    if (!sequenceIdxs) die("Out of memory indexing: %s\n", pairFileName);
+
+    inputInfo info;
+    info.numPairs = numPairs;
+    info.numBytes = numBytes;
+    info.numCells = 0;
+    info.minReferenceLength = SIZE_MAX;
+    info.minQueryLength = SIZE_MAX;
+    info.maxReferenceLength = 0;
+    info.maxQueryLength = 0;
+    double sumRef = 0, sumQry = 0;
+
+    // walk the buffer line by line; line 3k is ignored, 3k+1 is the reference, 3k+2 the query
+    size_t lineStart = 0, line = 0, pair = 0;
+    for (size_t i = 0; i < numBytes && pair < kInputCap; i++) {
+        if (sequences[i] != '\n') continue;
+        sequences[i] = '\0';
+        const size_t len = i - lineStart;
+        switch (line % 3) {
+        case 1:
+            sequenceIdxs[pair].referenceIdx = (int)lineStart;
+            sequenceIdxs[pair].referenceSize = (int)len;
+            sumRef += (double)len;
+            info.maxReferenceLength = std::max(info.maxReferenceLength, len);
+            info.minReferenceLength = std::min(info.minReferenceLength, len);
+            break;
+        case 2:
+            sequenceIdxs[pair].queryIdx = (int)lineStart;
+            sequenceIdxs[pair].querySize = (int)len;
+            sumQry += (double)len;
+            info.maxQueryLength = std::max(info.maxQueryLength, len);
+            info.minQueryLength = std::min(info.minQueryLength, len);
+            // the reference multiplies two ints here (parseInput.cpp:100); identical for every realistic input
+            info.numCells += (size_t)(sequenceIdxs[pair].referenceSize * sequenceIdxs[pair].querySize);
+            pair++;
+            break;
+        default: break;
+        }
+        lineStart = i + 1;
+        line++;
+    }
+    if (pair == kInputCap) info.numPairs = kInputCap;
+    info.avgReferenceLength = info.numPairs ? sumRef / (double)info.numPairs : 0.0;
+    info.avgQueryLength = info.numPairs ? sumQry / (double)info.numPairs : 0.0;
+    return info;
+}
+
+void printParsedFile(const size_t numPairs, const seqPair *idx, const char *sequences) {
+    for (size_t p = 0; p < numPairs; p++)
+        printf("Pair: %zu Reference: %c, Reference Size: %d, Query: %c, Query Size: %d\n", p, sequences[idx[p].referenceIdx],
+               idx[p].referenceSize, sequences[idx[p].queryIdx], idx[p].querySize);
+}
+
+void cleanupParsedFile(seqPair *sequenceIdxs, char *sequences) {
+    free(sequenceIdxs);
+    free(sequences);
+}

@@ -1,0 +1,35 @@
+// parseInput.h -- flat batch input of the reference (c++/parseInput.h:9-35): a pairs file has 3 lines per pair
+// (seed/score line -- ignored --, reference, query).  parseInput() loads the whole file into one malloc'ed buffer,
+// turns every '\n' into '\0' and returns, per pair, byte offsets + lengths into that buffer.  The struct layouts are
+// the reference's (seqPair is also the C ABI's dpx_seq_pair).
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define PRINT_PARSED_PAIRS
+
+struct inputInfo {
+    size_t numPairs;
+    size_t numBytes;
+    size_t numCells; // sum of referenceSize * querySize: the denominator of GCUPS
+    size_t minReferenceLength;
+    size_t minQueryLength;
+    size_t maxReferenceLength;
+    size_t maxQueryLength;
+    double avgReferenceLength;
+    double avgQueryLength;
+};
+
+struct seqPair {
+    int referenceIdx;
+    int referenceSize;
+    int queryIdx;
+    int querySize;
+};
+
+inputInfo parseInput(const char *pairFileName, seqPair *&sequence_indices, char *&sequences);
+void printParsedFile(const size_t numPairs, const seqPair *sequence_indices, const char *sequences);
+void cleanupParsedFile(seqPair *sequence_indices, char *sequences);

@@ -1,0 +1,93 @@
+"""GPU drop-in tests of the C++ host mirror (dpx_gpu_genomics_project_amd/hostcpp):
+
+* oracle/_ref/main_dropin_{LSW,LNW,ANW} -- the reference's OWN c++/main.cpp, compiled unchanged against the mirror's
+  headers and libdpxalign.so (hostcpp/Makefile `dropin`; built in the container that has /root/reference, the binary
+  travels to the GPU box) -- must print, after reordering by pair number (its 20 pthreads print in any order, which
+  is what scripts/reorderOutput.py exists for), exactly the blocks the reference's CPU classes print.
+* dpx_cpu_main (same shape, run-time algorithm flag, tail fixed) and dpx_main (batched, pipelined GPU driver).
+"""
+import gzip
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle_py as O
+from dpx_gpu_genomics_project_amd.synth import make_ragged_batch, write_pairs_file
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+HOST = os.path.join(ROOT, "dpx_gpu_genomics_project_amd", "hostcpp")
+W = {"LSW": ["-match", "3", "-mismatch", "-1", "-open", "-2"], "LNW": ["-match", "3", "-mismatch", "-1", "-open", "-2"],
+     "ANW": ["-match", "3", "-mismatch", "-1", "-open", "-3", "-extend", "-1"]}
+
+
+def golden(algo):
+    return gzip.open(os.path.join(G, f"short400_{algo}.out.gz"), "rb").read().decode("latin-1")
+
+
+def blocks_sorted(stdout):
+    """Split a driver's stdout into (header, {pair: block}, footer); a block starts at '<n> | <score>' and has 4 lines."""
+    lines = stdout.split("\n")
+    out, i, header, footer = {}, 0, [], []
+    while i < len(lines):
+        m = re.match(r"^(\d+) \| (-?\d+)$", lines[i])
+        if m:
+            out[int(m.group(1))] = "\n".join(lines[i:i + 4]) + "\n"
+            i += 4
+        else:
+            (footer if out else header).append(lines[i])
+            i += 1
+    return header, out, footer
+
+
+def run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True, encoding="latin-1", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
+def test_reference_main_cpp_drops_onto_the_engine(algo):
+    exe = os.path.join(ROOT, "oracle", "_ref", f"main_dropin_{algo}")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_dropin_* not built (needs /root/reference at build time)")
+    out = run([exe, "-pairs", os.path.join(G, "short400.txt")] + W[algo])
+    header, blocks, footer = blocks_sorted(out)
+    assert header[0].startswith("Parsing input file: ") and header[1] == "Pair # | Score"
+    assert any(l.startswith("Elapsed time (usec): ") for l in footer) and "Cleaning up" in footer
+    assert sorted(blocks) == list(range(400))
+    assert "".join(blocks[p] for p in range(400)) == golden(algo)
+
+
+@pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
+def test_class_driver_and_batched_driver_match_reference_stdout(algo):
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    pairs = os.path.join(G, "short400.txt")
+    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_cpu_main"), "-pairs", pairs] + W[algo] + ["-algo", algo]))
+    assert "".join(blocks[p] for p in range(400)) == golden(algo)
+    # batched driver prints in input order; 3 uneven batches exercise the printer pipeline
+    out = run([os.path.join(HOST, "dpx_main"), "-pairs", pairs] + W[algo] + ["-algo", algo, "-batch", "150"])
+    start = out.index("Pair # | Score\n") + len("Pair # | Score\n")
+    end = out.index("Elapsed time (usec): ")
+    assert out[start:end] == golden(algo)
+    assert re.search(r"^GCUPS: \d+\.\d+$", out, re.M) and "Num Pairs: 400" in out
+
+
+def test_tail_pairs_are_not_dropped(tmp_path):
+    """The reference main drops pairs past the last full 400 (c++/main.cpp:169); the mirror's drivers must not."""
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    sb = make_ragged_batch(37, 30, 60, 40, 70, seed=12)
+    path = str(tmp_path / "p37.txt")
+    write_pairs_file(sb, path)
+    want = ""
+    for p in range(37):
+        o = O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2)
+        a, b, c = ("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)
+        want += f"{p} | {o.score}\n{a}\n{b}\n{c}\n"
+    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_cpu_main"), "-pairs", path] + W["LSW"]))
+    assert "".join(blocks[p] for p in range(37)) == want
+    out = run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W["LSW"] + ["-algo", "BSW", "-band", "1000"])
+    assert out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time")] == want
