@@ -48,7 +48,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdpxalign.so")
+    """In-tree library; DPX_LIB may point at an experimental build (tools/ A-B runs)."""
+    return os.environ.get("DPX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdpxalign.so")
 
 
 def load() -> C.CDLL:

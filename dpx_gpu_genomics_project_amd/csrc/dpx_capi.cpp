@@ -71,6 +71,11 @@ struct dpx_batch {
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
     size_t ldsBytes = 0;
+    /* packed two-pairs-per-wave path (LNW/LSW with matrices): couples of equal-shaped pairs + leftover singles */
+    bool packed = false;
+    int32_t *dCouples = nullptr;
+    dpx_fill_args pkArgs{};
+    size_t pkLdsBytes = 0;
     /* traceback (lazy): device line buffers + host mirror */
     uint64_t *dTbOff = nullptr;
     char *dTb = nullptr;
@@ -175,6 +180,7 @@ int dpx_batch_destroy(dpx_batch *b) {
     (void)hipFree(b->dSeq);
     (void)hipFree(b->dPairs);
     (void)hipFree(b->dOrder);
+    (void)hipFree(b->dCouples);
     (void)hipFree(b->dMat);
     (void)hipFree(b->dScore);
     (void)hipFree(b->dEndRow);
@@ -293,22 +299,63 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
     if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
     if (b->store && b->matElems) CREATE_TRY(hipMalloc((void **)&b->dMat, b->matElems * sizeof(int16_t)));
-    if (ragged) { /* longest-processing-time-first launch order evens out the tail of a ragged batch */
-        std::vector<int32_t> order(numPairs);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
+    std::vector<int32_t> singles, couples;
+    /* "+Opt" packed path: parity-green, but on MI355X it measured 5-10 % slower than one pair per wave because the fill is
+     * bound by HBM stores, not VALU (profiles/README.md) -- opt-in with DPX_PACKED=1 */
+    bool usePacked = false;
+    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0;
+    usePacked = usePacked && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
+    if (usePacked) {
+        std::vector<int32_t> idx;
+        idx.reserve(numPairs);
+        for (size_t i = 0; i < numPairs; i++) {
+            if (b->pairs[i].m > 0 && b->pairs[i].n > 0) idx.push_back((int32_t)i);
+            else singles.push_back((int32_t)i);
+        }
+        if (ragged)
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) {
+                const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
+                const uint64_t cx = (uint64_t)X.m * X.n, cy = (uint64_t)Y.m * Y.n;
+                if (cx != cy) return cx > cy; /* longest first */
+                if (X.m != Y.m) return X.m > Y.m;
+                return X.n > Y.n;
+            });
+        for (size_t i = 0; i < idx.size();) {
+            if (i + 1 < idx.size() && b->pairs[idx[i]].m == b->pairs[idx[i + 1]].m && b->pairs[idx[i]].n == b->pairs[idx[i + 1]].n) {
+                couples.push_back(idx[i]);
+                couples.push_back(idx[i + 1]);
+                i += 2;
+            } else {
+                singles.push_back(idx[i]);
+                i += 1;
+            }
+        }
+        b->packed = !couples.empty();
+    }
+    if (b->packed) {
+        CREATE_TRY(hipMalloc((void **)&b->dCouples, couples.size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    } else if (ragged) {
+        singles.resize(numPairs);
+        std::iota(singles.begin(), singles.end(), 0);
+    }
+    if (!singles.empty()) {
+        std::stable_sort(singles.begin(), singles.end(), [&](int32_t x, int32_t y) {
             return (uint64_t)b->pairs[x].m * b->pairs[x].n > (uint64_t)b->pairs[y].m * b->pairs[y].n;
         });
-        CREATE_TRY(hipMalloc((void **)&b->dOrder, numPairs * sizeof(int32_t)));
-        CREATE_TRY(hipMemcpy(b->dOrder, order.data(), numPairs * sizeof(int32_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void **)&b->dOrder, singles.size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    const size_t numSingles = b->packed ? singles.size() : numPairs;
+    const size_t numCouples = couples.size() / 2;
 #undef CREATE_TRY
 
     dpx_fill_args &a = b->args;
     a.seq = b->dSeq;
     a.pairs = b->dPairs;
     a.order = b->dOrder;
-    a.numPairs = (int32_t)numPairs;
+    a.numPairs = (int32_t)numSingles;
     a.match = params->match; a.mismatch = params->mismatch;
     a.gapOpen = params->gapOpen; a.gapExtend = params->gapExtend; a.band = params->band;
     a.mat = b->dMat;
@@ -316,8 +363,28 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     a.ldsPerWave = (uint32_t)perWave;
     a.ldsEdge2Off = (uint32_t)edgeBytes;
     a.ldsRefOff = banded ? (uint32_t)qBytes : (uint32_t)(edgeBytes * nEdges);
+    if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
+        dpx_fill_args &k = b->pkArgs;
+        k = a;
+        k.order = b->dCouples;
+        k.numPairs = (int32_t)numCouples;
+        const size_t pkEdge = align_up((size_t)(b->maxN + 2) * 4, 16);
+        const size_t pkRef = align_up(((size_t)b->maxN + 128) * 2, 16);
+        k.ldsPerWave = (uint32_t)(pkEdge + pkRef);
+        k.ldsRefOff = (uint32_t)pkEdge;
+        b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
+        if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+    }
     *out = b;
     return DPX_OK;
+}
+
+static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
+    if (b->packed) {
+        hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+        if (e != hipSuccess) return e;
+    }
+    return dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
 }
 
 int dpx_batch_fill(dpx_batch *b, void *stream) {
@@ -325,7 +392,7 @@ int dpx_batch_fill(dpx_batch *b, void *stream) {
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    HIP_TRY(dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s));
+    HIP_TRY(launch_all(b, s));
     b->lastStream = s;
     b->filled = true;
     b->tbValid = false;
@@ -341,7 +408,7 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, b->stream));
     for (int i = 0; i < repeats; i++) {
-        hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, b->stream);
+        hipError_t e = launch_all(b, b->stream);
         if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hip_fail(e, "dpx_launch_fill"); }
     }
     HIP_TRY(hipEventRecord(e1, b->stream));
@@ -427,7 +494,7 @@ static int run_traceback(dpx_batch *b) {
         b->hTbLen.resize(np);
     }
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
-    HIP_TRY(dpx_launch_traceback(b->args, b->kernelAlgo, b->R, b->planes, b->dTbOff, b->dTb, b->dTbLen, b->stream));
+    HIP_TRY(dpx_launch_traceback(b->args, (int)b->numPairs, b->kernelAlgo, b->R, b->planes, b->dTbOff, b->dTb, b->dTbLen, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (np) {
         HIP_TRY(hipMemcpy(b->hTb.data(), b->dTb, b->hTb.size(), hipMemcpyDeviceToHost));

@@ -29,26 +29,37 @@ using dpx::wave_shr1;
 using dpx::wave_shl1;
 
 /* ---- coalesced tile store: R int32 scores -> R int16, 2*R bytes per lane, lanes contiguous ---- */
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+/* matrices are written once and never re-read by the fill: DPX_NT_STORES selects `global_store ... nt` */
+#ifndef DPX_NT_STORES
+#define DPX_NT_STORES 0
+#endif
+template <class V>
+__device__ __forceinline__ void stream_store(V *dst, V v) {
+#if DPX_NT_STORES
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
+
 template <int R>
 __device__ __forceinline__ void store_tile(int16_t *dst, const int (&v)[R]) {
     if constexpr (R == 1) {
         *dst = (int16_t)v[0];
     } else if constexpr (R == 2) {
-        *reinterpret_cast<uint32_t *>(dst) = pack_lo16(v[0], v[1]);
+        stream_store(reinterpret_cast<uint32_t *>(dst), pack_lo16(v[0], v[1]));
     } else if constexpr (R == 4) {
-        uint2 w;
-        w.x = pack_lo16(v[0], v[1]);
-        w.y = pack_lo16(v[2], v[3]);
-        *reinterpret_cast<uint2 *>(dst) = w;
+        u32x2 w = {pack_lo16(v[0], v[1]), pack_lo16(v[2], v[3])};
+        stream_store(reinterpret_cast<u32x2 *>(dst), w);
     } else {
 #pragma unroll
         for (int q = 0; q < R / 8; q++) {
-            uint4 w;
-            w.x = pack_lo16(v[8 * q + 0], v[8 * q + 1]);
-            w.y = pack_lo16(v[8 * q + 2], v[8 * q + 3]);
-            w.z = pack_lo16(v[8 * q + 4], v[8 * q + 5]);
-            w.w = pack_lo16(v[8 * q + 6], v[8 * q + 7]);
-            reinterpret_cast<uint4 *>(dst)[q] = w;
+            u32x4 w = {pack_lo16(v[8 * q + 0], v[8 * q + 1]), pack_lo16(v[8 * q + 2], v[8 * q + 3]),
+                       pack_lo16(v[8 * q + 4], v[8 * q + 5]), pack_lo16(v[8 * q + 6], v[8 * q + 7])};
+            stream_store(reinterpret_cast<u32x4 *>(dst) + q, w);
         }
     }
 }
@@ -220,6 +231,211 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             a.score[p] = v;
             a.endRow[p] = m;
             a.endCol[p] = n;
+        }
+    }
+}
+
+/* =====================================================================================================
+ * "+Opt": packed two-pairs-per-wave linear fill (the reference's V18/V19 idea, cuda/LNW/LinearNeedlemanWunschV18.cu:
+ * 112-341 and the unfinished cuda/LinearSmithWatermanOpt.cu: one warp computes two pairs with __vibmax_s16x2).
+ * Every VGPR holds pair A in its high half and pair B in its low half (V19.cu:16-24); the cell update runs on the
+ * VOP3P packed-int16 pipe: v_xor (chars), v_pk_min_u16 (0/1 "differs"), v_pk_mad_i16 (s = differs*(mismatch-match)+match),
+ * v_pk_max_i16 / v_pk_add_i16.  One DPP move carries both pairs to the next lane.  Both pairs must have the same
+ * (m, n); the host couples equal-shaped pairs and sends leftovers to k_linear_fill.  Matrices are written in the
+ * same per-pair wavefront-tiled layout, so export and traceback do not care which kernel filled a pair.
+ * SW start cell: the loop only keeps a packed per-row running maximum; the (first row, first column) of the maximum
+ * is resolved afterwards by re-reading that single row of the matrix this wave just wrote.
+ * ===================================================================================================== */
+using dpx::s16x2;
+using dpx::u16x2;
+using dpx::as_s16x2;
+using dpx::as_u16x2;
+using dpx::as_u32;
+
+template <int R>
+struct PkState {
+    uint32_t Hl[R];   /* packed H[row][j-1] */
+    uint32_t qc[R];   /* packed query characters (16-bit lanes) */
+    uint32_t rmax[R]; /* SW: packed per-row running maximum */
+    uint32_t dtop;
+};
+
+__device__ __forceinline__ uint32_t pk_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); } /* {lo.hi16, hi.hi16} */
+
+template <int R>
+__device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, const uint32_t (&v)[R]) {
+    /* pair A = high halves, pair B = low halves; R/2 dwords each */
+    if constexpr (R == 2) {
+        *reinterpret_cast<uint32_t *>(dstA) = pk_hi16(v[0], v[1]);
+        *reinterpret_cast<uint32_t *>(dstB) = pack_lo16((int)v[0], (int)v[1]);
+    } else if constexpr (R == 4) {
+        uint2 a, b;
+        a.x = pk_hi16(v[0], v[1]); a.y = pk_hi16(v[2], v[3]);
+        b.x = pack_lo16((int)v[0], (int)v[1]); b.y = pack_lo16((int)v[2], (int)v[3]);
+        *reinterpret_cast<uint2 *>(dstA) = a;
+        *reinterpret_cast<uint2 *>(dstB) = b;
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 8; q++) {
+            uint4 a, b;
+            a.x = pk_hi16(v[8 * q + 0], v[8 * q + 1]); a.y = pk_hi16(v[8 * q + 2], v[8 * q + 3]);
+            a.z = pk_hi16(v[8 * q + 4], v[8 * q + 5]); a.w = pk_hi16(v[8 * q + 6], v[8 * q + 7]);
+            b.x = pack_lo16((int)v[8 * q + 0], (int)v[8 * q + 1]); b.y = pack_lo16((int)v[8 * q + 2], (int)v[8 * q + 3]);
+            b.z = pack_lo16((int)v[8 * q + 4], (int)v[8 * q + 5]); b.w = pack_lo16((int)v[8 * q + 6], (int)v[8 * q + 7]);
+            reinterpret_cast<uint4 *>(dstA)[q] = a;
+            reinterpret_cast<uint4 *>(dstB)[q] = b;
+        }
+    }
+}
+
+template <int R, bool LOCAL, bool MASKED>
+__device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
+                                        const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP, const uint32_t e0,
+                                        const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB) {
+    const int j = t - lane + 1;
+    const uint32_t upin = (uint32_t)wave_shr1((int)st.Hl[R - 1], (int)e0);
+    bool active = true;
+    if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
+    if (active) {
+        uint32_t u = upin, d = st.dtop;
+        const uint32_t onesP = 0x00010001u;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t left = st.Hl[r];
+            const uint32_t differs = dpx::pk_min_u16_raw(st.qc[r] ^ rcP, onesP);                 /* 0 / 1 per half */
+            const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));         /* match or mismatch per half */
+            const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP);
+            s16x2 h = dpx::pk_max(g, (s16x2)(as_s16x2(d) + sc));
+            if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+            d = left;
+            u = as_u32(h);
+            st.Hl[r] = u;
+            if constexpr (LOCAL) st.rmax[r] = as_u32(dpx::pk_max(as_s16x2(st.rmax[r]), h));
+        }
+        st.dtop = upin;
+        store_tile_pk<R>(tileA, tileB, st.Hl);
+        if (writeEdge && lane == 63) edge[j] = st.Hl[R - 1];
+    }
+}
+
+/* first column of row i (1-based) whose stored score equals `want`; whole wave cooperates; 0 if none */
+template <int R>
+__device__ __forceinline__ int first_col_equal(const int16_t *Hp, int i, int n, int want, int lane) {
+    const int i0 = i - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
+    const size_t rowBase = (((size_t)k * (size_t)(n + 63) + (size_t)l) * 64u + (size_t)l) * R + r; /* column 1 */
+    for (int j0 = 1; j0 <= n; j0 += 64) {
+        const int j = j0 + lane;
+        const int v = (j <= n) ? (int)Hp[rowBase + (size_t)(j - 1) * 64u * R] : -32768;
+        const unsigned long long hit = __ballot(v == want);
+        if (hit) return j0 + __ffsll((long long)hit) - 1;
+    }
+    return 0;
+}
+
+template <int R, bool LOCAL>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* couple index */
+    if (c >= a.numPairs) return;
+    const int pA = a.order[2 * c], pB = a.order[2 * c + 1];
+    const dpx_pair_dev prA = a.pairs[pA], prB = a.pairs[pB];
+    const int n = prA.n, m = prA.m; /* host guarantees prB.n == n, prB.m == m, both > 0 */
+    const unsigned char *refA = reinterpret_cast<const unsigned char *>(a.seq + prA.refIdx);
+    const unsigned char *refB = reinterpret_cast<const unsigned char *>(a.seq + prB.refIdx);
+    const unsigned char *qryA = reinterpret_cast<const unsigned char *>(a.seq + prA.qryIdx);
+    const unsigned char *qryB = reinterpret_cast<const unsigned char *>(a.seq + prB.qryIdx);
+    const int gap = a.gapOpen;
+    const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
+    const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
+    const uint32_t gapP = ((uint32_t)(uint16_t)gap << 16) | (uint16_t)gap;
+
+    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
+    uint32_t *edge = reinterpret_cast<uint32_t *>(my);                    /* packed edge[j], j = 0..n+1 */
+    uint16_t *refl = reinterpret_cast<uint16_t *>(my + a.ldsRefOff);      /* refl[64 + (j-1)] = A char << 8 | B char */
+    for (int x = lane; x < n; x += 64) refl[64 + x] = (uint16_t)((refA[x] << 8) | refB[x]);
+    for (int x = lane; x <= n + 1; x += 64) {
+        const uint16_t b = (uint16_t)(LOCAL ? 0 : x * gap);
+        edge[x] = ((uint32_t)b << 16) | b;
+    }
+    int16_t *HpA = a.mat + prA.matOff, *HpB = a.mat + prB.matOff;
+    const int W = n + 63;
+    const int S = dpx_tiled_stripes(m, R);
+    int bestA = 0, browA = 0, bestB = 0, browB = 0;
+    PkState<R> st;
+
+    for (int k = 0; k < S; k++) {
+        const int base = k * 64 * R;
+        const int row0 = base + lane * R;
+        const int nrows = min(max(m - row0, 0), R);
+        const bool laneHasRows = nrows > 0;
+        const bool hasNext = (k + 1 < S);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            st.qc[r] = (r < nrows) ? (((uint32_t)qryA[row0 + r] << 16) | qryB[row0 + r]) : 0x01000100u;
+            const uint16_t b = (uint16_t)(LOCAL ? 0 : (row0 + 1 + r) * gap);
+            st.Hl[r] = ((uint32_t)b << 16) | b;
+            st.rmax[r] = 0u;
+        }
+        { const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap); st.dtop = ((uint32_t)b << 16) | b; }
+        const size_t tileOff = ((size_t)k * (size_t)W * 64u + (size_t)lane) * R;
+        int16_t *tileA = HpA + tileOff, *tileB = HpB + tileOff;
+        const uint16_t *rp = refl + 64 - lane;
+        uint32_t rcN = rp[0];
+        uint32_t e0N = edge[1];
+#define DPX_PK_STEP(MASKED_, HASROWS_)                                                                                  \
+        {                                                                                                             \
+            const uint32_t rc16 = rcN, e0 = e0N;                                                                      \
+            rcN = rp[t + 1];                                                                                          \
+            e0N = edge[min(t + 2, n + 1)];                                                                            \
+            const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u); /* {A char, B char} -> 16-bit lanes */  \
+            pk_step<R, LOCAL, MASKED_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext,      \
+                                       tileA + (size_t)t * 64u * R, tileB + (size_t)t * 64u * R);                    \
+        }
+        const bool fast = (base + 64 * R <= m) && (n >= 64);
+        if (fast) {
+            int t = 0;
+            for (; t < 63; t++) DPX_PK_STEP(true, true)
+            for (; t < n; t++) DPX_PK_STEP(false, true)
+            for (; t < W; t++) DPX_PK_STEP(true, true)
+        } else {
+            for (int t = 0; t < W; t++) DPX_PK_STEP(true, laneHasRows)
+        }
+#undef DPX_PK_STEP
+        if constexpr (LOCAL) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int hA = (int)(int16_t)(st.rmax[r] >> 16), hB = (int)(int16_t)(st.rmax[r] & 0xFFFFu);
+                if (r < nrows && hA > bestA) { bestA = hA; browA = row0 + 1 + r; }
+                if (r < nrows && hB > bestB) { bestB = hB; browB = row0 + 1 + r; }
+            }
+        }
+    }
+
+    if constexpr (LOCAL) {
+        /* max score, then first row (c++/LinearSmithWaterman.cpp:145-157) ... */
+        const unsigned long long topA = wave_max_u64(((unsigned long long)(unsigned)bestA << 32) | (unsigned)(0x7FFFFFFF - browA));
+        const unsigned long long topB = wave_max_u64(((unsigned long long)(unsigned)bestB << 32) | (unsigned)(0x7FFFFFFF - browB));
+        const int mA = (int)(topA >> 32), rA = 0x7FFFFFFF - (int)(topA & 0xFFFFFFFFu);
+        const int mB = (int)(topB >> 32), rB = 0x7FFFFFFF - (int)(topB & 0xFFFFFFFFu);
+        /* ... then the first column of that row, re-read from the matrix this wave wrote (stores made visible first) */
+        __threadfence();
+        const int cA = mA > 0 ? first_col_equal<R>(HpA, rA, n, mA, lane) : 0;
+        const int cB = mB > 0 ? first_col_equal<R>(HpB, rB, n, mB, lane) : 0;
+        if (lane == 0) {
+            a.score[pA] = mA; a.endRow[pA] = mA > 0 ? rA : 0; a.endCol[pA] = cA;
+            a.score[pB] = mB; a.endRow[pB] = mB > 0 ? rB : 0; a.endCol[pB] = cB;
+        }
+    } else {
+        const int lastBase = (S - 1) * 64 * R;
+        const int lm = (m - 1 - lastBase) / R, rm = (m - 1 - lastBase) % R;
+        if (lane == lm) {
+            uint32_t v = st.Hl[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+            a.score[pA] = (int)(int16_t)(v >> 16); a.endRow[pA] = m; a.endCol[pA] = n;
+            a.score[pB] = (int)(int16_t)(v & 0xFFFFu); a.endRow[pB] = m; a.endCol[pB] = n;
         }
     }
 }
@@ -578,10 +794,10 @@ struct TbView {
     }
 };
 
-__global__ void k_traceback(const dpx_fill_args a, int algo, int R, int planes, const int32_t *endRow, const int32_t *endCol,
-                            const uint64_t *tbOff, char *tb, int32_t *tbLen) {
+__global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R, int planes, const int32_t *endRow,
+                            const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.numPairs) return;
+    if (p >= numPairs) return;
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
@@ -717,6 +933,12 @@ hipError_t launch_linear_R(const dpx_fill_args &a, bool local, bool store, dim3 
                  : launch_fill_kernel(k_linear_fill<R, false, false>, a, grid, lds, s);
 }
 
+template <int R>
+hipError_t launch_linear_pk_R(const dpx_fill_args &a, bool local, dim3 grid, size_t lds, hipStream_t s) {
+    return local ? launch_fill_kernel(k_linear_fill_pk<R, true>, a, grid, lds, s)
+                 : launch_fill_kernel(k_linear_fill_pk<R, false>, a, grid, lds, s);
+}
+
 template <int C>
 hipError_t launch_banded_C(const dpx_fill_args &a, bool store, dim3 grid, size_t lds, hipStream_t s) {
     const bool pb = ((a.band + 1) & 1) != 0; /* parity of step A = 0 */
@@ -770,6 +992,21 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
     return hipErrorInvalidValue;
 }
 
+/* packed two-pairs-per-wave linear fill: a.order = couples (2 ints each), a.numPairs = number of couples */
+hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
+    const bool local = algo == DPX_K_LSW;
+    switch (R) {
+    case 2: return launch_linear_pk_R<2>(a, local, grid, ldsBytes, stream);
+    case 4: return launch_linear_pk_R<4>(a, local, grid, ldsBytes, stream);
+    case 8: return launch_linear_pk_R<8>(a, local, grid, ldsBytes, stream);
+    case 16: return launch_linear_pk_R<16>(a, local, grid, ldsBytes, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream) {
     const size_t total = (size_t)(pr.m + 1) * (size_t)(pr.n + 1);
@@ -780,11 +1017,11 @@ hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int alg
     return hipGetLastError();
 }
 
-hipError_t dpx_launch_traceback(const dpx_fill_args &a, int algo, int R, int planes, const uint64_t *tbOff, char *tb,
-                                int32_t *tbLen, hipStream_t stream) {
-    if (a.numPairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)((a.numPairs + 63) / 64)), dim3(64), 0, stream, a, algo, R, planes, a.endRow,
-                       a.endCol, tbOff, tb, tbLen);
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, const uint64_t *tbOff,
+                                char *tb, int32_t *tbLen, hipStream_t stream) {
+    if (numPairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,
+                       a.endRow, a.endCol, tbOff, tb, tbLen);
     return hipGetLastError();
 }
 

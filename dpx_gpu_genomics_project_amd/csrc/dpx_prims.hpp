@@ -105,6 +105,19 @@ __device__ __forceinline__ uint32_t viaddmin_s16x2_relu(uint32_t a, uint32_t b, 
 __device__ __forceinline__ int wave_shr1(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int wave_shl1(int v, int lane63) { return __builtin_amdgcn_update_dpp(lane63, v, 0x130, 0xf, 0xf, false); }
 
+/* hipcc lowers a packed `min(x,1)*k+c` into per-half v_cmp/v_cndmask/v_perm (5 instructions); these two keep it on the
+ * VOP3P pipe.  Register-only single instructions: no memory, no wait states needed around them. */
+__device__ __forceinline__ uint32_t pk_min_u16_raw(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_i16_raw(uint32_t a, uint32_t b, uint32_t c) { /* per half: a*b + c (wraps) */
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 /* pack the low halves of two ints into one dword: one v_perm_b32 */
 __device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
