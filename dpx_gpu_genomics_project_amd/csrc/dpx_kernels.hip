@@ -36,6 +36,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DPX_NT_STORES
 #define DPX_NT_STORES 0
 #endif
+#ifndef DPX_EXP_NOCOMPUTE
+#define DPX_EXP_NOCOMPUTE 0
+#endif
+#ifndef DPX_EXP_NORAMPSTORE
+#define DPX_EXP_NORAMPSTORE 0
+#endif
 template <class V>
 __device__ __forceinline__ void stream_store(V *dst, V v) {
 #if DPX_NT_STORES
@@ -100,6 +106,9 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
     if (active) {
         int u = upin, d = st.dtop;
         const unsigned negj = 0xFFFFu - (unsigned)j;
+#if DPX_EXP_NOCOMPUTE /* ablation build only (tools/): stores without the recurrence */
+        st.Hl[0] += u + d + rc + (int)negj;
+#else
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int left = st.Hl[r];
@@ -113,10 +122,15 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
             st.Hl[r] = h;
             if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)h << 16) | negj);
         }
+#endif
         st.dtop = upin;
-        if constexpr (STORE) store_tile<R>(tileDst, st.Hl);
         if (writeEdge && lane == 63) edge[j] = (int16_t)st.Hl[R - 1];
     }
+    /* Every lane stores, also lanes that are not on a real cell during the skew ramps: the wave then always writes
+     * its whole 64*R*2-byte chunk.  Partial chunks (masked stores) measured ~2.5x the cost of full ones -- a chunk
+     * with a partly written 64-B sector becomes a read-modify-write at the HBM.  The extra bytes land in the skew
+     * padding of the pair's block, which nothing ever reads. */
+    if constexpr (STORE && !(MASKED && DPX_EXP_NORAMPSTORE)) store_tile<R>(tileDst, st.Hl);
 }
 
 template <int R, bool LOCAL, bool STORE>
@@ -313,9 +327,9 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
             if constexpr (LOCAL) st.rmax[r] = as_u32(dpx::pk_max(as_s16x2(st.rmax[r]), h));
         }
         st.dtop = upin;
-        store_tile_pk<R>(tileA, tileB, st.Hl);
         if (writeEdge && lane == 63) edge[j] = st.Hl[R - 1];
     }
+    store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks, also on the skew ramps (see lin_step) */
 }
 
 /* first column of row i (1-based) whose stored score equals `want`; whole wave cooperates; 0 if none */
@@ -483,15 +497,15 @@ __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int
             st.Dl[r] = Dn;
         }
         st.dtop = upH;
-        if constexpr (STORE) {
-            store_tile<R>(tileDst, st.Hl);
-            store_tile<R>(tileDst + 64 * R, st.Il);
-            store_tile<R>(tileDst + 128 * R, st.Dl);
-        }
         if (writeEdge && lane == 63) {
             edgeH[j] = (int16_t)st.Hl[R - 1];
             edgeD[j] = (int16_t)st.Dl[R - 1];
         }
+    }
+    if constexpr (STORE) { /* whole chunks, also on the skew ramps (see lin_step) */
+        store_tile<R>(tileDst, st.Hl);
+        store_tile<R>(tileDst + 64 * R, st.Il);
+        store_tile<R>(tileDst + 128 * R, st.Dl);
     }
 }
 
