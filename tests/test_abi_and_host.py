@@ -78,3 +78,13 @@ def test_shard_range_covers_everything_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for (a, b), (c, d) in zip(spans, spans[1:]):
                 assert b == c and a <= b and c <= d
+
+
+def test_reorder_output_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reorder_output", os.path.join(ROOT, "tools", "reorder_output.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = "Parsing input file: x\nPair # | Score\n2 | 0\n\n\n\n0 | 5\nAC\n**\nAC\n1 | -3\nA_\n* \nAG\nElapsed time (usec): 7\nCleaning up\n"
+    want = "Parsing input file: x\nPair # | Score\n0 | 5\nAC\n**\nAC\n1 | -3\nA_\n* \nAG\n2 | 0\n\n\n\nElapsed time (usec): 7\nCleaning up\n"
+    assert mod.reorder(text) == want

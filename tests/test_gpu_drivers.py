@@ -91,3 +91,13 @@ def test_tail_pairs_are_not_dropped(tmp_path):
     assert "".join(blocks[p] for p in range(37)) == want
     out = run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W["LSW"] + ["-algo", "BSW", "-band", "1000"])
     assert out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time")] == want
+
+
+def test_reference_testFakeDPX_passes_on_device_primitives():
+    """The reference's own c++/testFakeDPX.cpp (74 asserts), compiled unchanged against hostcpp/FakeDPX.hpp, whose every
+    call runs the CDNA4 mapping of the primitive on the GPU (dpx_prim_eval)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "testFakeDPX_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/testFakeDPX_dropin not built (needs /root/reference at build time)")
+    out = run([exe])
+    assert "PASSED ALL ASSERTIONS FOR INSTRUCTION CHECKING!!" in out
