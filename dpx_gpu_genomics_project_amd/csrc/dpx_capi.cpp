@@ -253,11 +253,11 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const bool banded = kernelAlgo == DPX_ALGO_BSW;
 
     /* matrix placement + algorithmic bytes: int16 cells incl. borders, sequences, 16 B pair record, 12 B result */
-    uint64_t off = 0;
     for (size_t i = 0; i < numPairs; i++) {
         dpx_pair_dev &pd = b->pairs[i];
-        pd.matOff = off;
-        if (b->store) off += banded ? dpx_band_elems(pd.m, pd.n, params->band) : dpx_tiled_elems(pd.m, pd.n, b->R, b->planes);
+        pd.matOff = 0;
+        pd.chunkStride = 0;
+        pd.pad_ = 0;
         b->algBytes += (uint64_t)pd.m + (uint64_t)pd.n + 16u + 12u;
         if (b->store) {
             if (banded) { /* 2 B per in-band cell */
@@ -273,14 +273,14 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
             }
         }
     }
-    b->matElems = off;
 
     /* LDS per wave: edge row(s) of int16 [n+2] + staged reference [n+128] */
     const size_t edgeBytes = align_up((size_t)(b->maxN + 2) * 2, 16);
     const size_t nEdges = params->algo == DPX_ALGO_ANW ? 2 : 1;
     const size_t refBytes = align_up((size_t)b->maxN + 128, 16);
     const size_t qBytes = align_up((size_t)b->maxM + 16, 16);
-    const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes;
+    const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 16, 16); /* staged query of the rolling multi-stripe schedule */
+    const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes + rollQ;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 
@@ -297,8 +297,6 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     CREATE_TRY(hipMalloc((void **)&b->dEndRow, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void **)&b->dEndCol, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
-    if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
-    if (b->store && b->matElems) CREATE_TRY(hipMalloc((void **)&b->dMat, b->matElems * sizeof(int16_t)));
     /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
     std::vector<int32_t> singles, couples;
     /* "+Opt" packed path: parity-green, but on MI355X it measured 5-10 % slower than one pair per wave because the fill is
@@ -349,6 +347,42 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     }
     const size_t numSingles = b->packed ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
+
+    /* matrix placement (dpx_layout.h): pairs that are launched next to each other are interleaved chunk by chunk in
+     * groups of `group` waves, so a group writes one compact moving window instead of `group` far-apart streams */
+    if (b->store) {
+        int group = 64;
+        if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 4096) group = v; }
+        const uint32_t chunkElems = banded ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
+        auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
+            return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
+        };
+        uint64_t off = 0;
+        auto place = [&](const std::vector<int32_t> &slots, size_t slotsPerGroup) { /* slots in launch order */
+            for (size_t s0 = 0; s0 < slots.size(); s0 += slotsPerGroup) {
+                const size_t cnt = std::min(slotsPerGroup, slots.size() - s0);
+                uint64_t maxChunks = 0;
+                for (size_t g = 0; g < cnt; g++) maxChunks = std::max(maxChunks, chunksOf(b->pairs[slots[s0 + g]]));
+                for (size_t g = 0; g < cnt; g++) {
+                    dpx_pair_dev &pd = b->pairs[slots[s0 + g]];
+                    pd.matOff = off + (uint64_t)g * chunkElems;
+                    pd.chunkStride = (uint32_t)(cnt * chunkElems);
+                }
+                off += maxChunks * (uint64_t)cnt * chunkElems;
+            }
+        };
+        if (b->packed) place(couples, (size_t)group * 2); /* one wave = two adjacent slots */
+        if (b->packed || !singles.empty()) {
+            place(singles, (size_t)group);
+        } else { /* launch order == pair order */
+            std::vector<int32_t> ident(numPairs);
+            std::iota(ident.begin(), ident.end(), 0);
+            place(ident, (size_t)group);
+        }
+        b->matElems = off;
+    }
+    if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
+    if (b->store && b->matElems) CREATE_TRY(hipMalloc((void **)&b->dMat, b->matElems * sizeof(int16_t)));
 #undef CREATE_TRY
 
     dpx_fill_args &a = b->args;
@@ -363,6 +397,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     a.ldsPerWave = (uint32_t)perWave;
     a.ldsEdge2Off = (uint32_t)edgeBytes;
     a.ldsRefOff = banded ? (uint32_t)qBytes : (uint32_t)(edgeBytes * nEdges);
+    a.ldsQryOff = banded ? 0u : (uint32_t)(edgeBytes * nEdges + refBytes);
     if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
         dpx_fill_args &k = b->pkArgs;
         k = a;

@@ -27,6 +27,7 @@ typedef struct dpx_fill_args {
     uint32_t ldsPerWave;        /* bytes of dynamic LDS per wave */
     uint32_t ldsEdge2Off;       /* ANW: offset of the second edge row (D) */
     uint32_t ldsRefOff;         /* offset of the staged reference characters */
+    uint32_t ldsQryOff;         /* offset of the staged query characters (rolling multi-stripe path) */
 } dpx_fill_args;
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);

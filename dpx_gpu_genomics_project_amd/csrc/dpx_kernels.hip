@@ -27,6 +27,11 @@ namespace {
 using dpx::pack_lo16;
 using dpx::wave_shr1;
 using dpx::wave_shl1;
+using dpx::s16x2;
+using dpx::u16x2;
+using dpx::as_s16x2;
+using dpx::as_u16x2;
+using dpx::as_u32;
 
 /* ---- coalesced tile store: R int32 scores -> R int16, 2*R bytes per lane, lanes contiguous ---- */
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -41,6 +46,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef DPX_EXP_NORAMPSTORE
 #define DPX_EXP_NORAMPSTORE 0
+#endif
+#ifndef DPX_SW_RESCAN
+#define DPX_SW_RESCAN 0
 #endif
 template <class V>
 __device__ __forceinline__ void stream_store(V *dst, V v) {
@@ -89,11 +97,110 @@ template <int R, bool LOCAL>
 struct LinState {
     int Hl[R];        /* H[row][j-1] of the lane's R rows (the "left" values, then overwritten by H[row][j]) */
     int qc[R];        /* query characters of the lane's rows */
-    unsigned key[R];  /* SW: per-row running max of (H << 16 | 0xFFFF - j): max score, then smallest column */
+    unsigned key[R];  /* SW, score-only: per-row running max of (H << 16 | 0xFFFF - j): max score, then smallest column */
+    unsigned rmaxP[(R + 1) / 2]; /* SW with matrices: running row maxima, two rows per dword (v_pk_max_u16 on the
+                                    dwords packed for the store anyway); the column is re-read from the matrix at the end */
     int dtop;         /* H[row0][j-1]: diagonal of the lane's top row */
 };
 
-template <int R, bool LOCAL, bool STORE, bool MASKED>
+/* the R chained cells of one lane for one column (shared by the striped and the rolling schedule) */
+template <int R, bool LOCAL, bool KEYS>
+__device__ __forceinline__ void lin_cells(LinState<R, LOCAL> &st, const int upin, const int rc, const int j, const int match,
+                                          const int mismatch, const int gap) {
+    int u = upin, d = st.dtop;
+    const unsigned negj = 0xFFFFu - (unsigned)j;
+#if DPX_EXP_NOCOMPUTE /* ablation build only (tools/): stores without the recurrence */
+    st.Hl[0] += u + d + rc + (int)negj;
+#else
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int left = st.Hl[r];
+        const int s = (st.qc[r] == rc) ? match : mismatch;
+        const int g = max(u, left) + gap;
+        int h;
+        if constexpr (LOCAL) h = max(max(g, d + s), 0); /* v_max3_i32 */
+        else h = max(g, d + s);
+        d = left;
+        u = h;
+        st.Hl[r] = h;
+        if constexpr (LOCAL && KEYS) st.key[r] = max(st.key[r], ((unsigned)h << 16) | negj);
+    }
+#endif
+    st.dtop = upin;
+}
+
+/* pack the lane's R scores into R/2 dwords (the store format); SW additionally folds them into the packed row maxima */
+template <int R, bool LOCAL, bool TRACK>
+__device__ __forceinline__ void lin_pack(LinState<R, LOCAL> &st, uint32_t (&w)[(R + 1) / 2]) {
+#pragma unroll
+    for (int q = 0; q < R / 2; q++) {
+        w[q] = pack_lo16(st.Hl[2 * q], st.Hl[2 * q + 1]);
+        if constexpr (LOCAL && TRACK) st.rmaxP[q] = as_u32(dpx::pk_max(as_u16x2(st.rmaxP[q]), as_u16x2(w[q])));
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_words(int16_t *dst, const uint32_t (&w)[(R + 1) / 2]) {
+    if constexpr (R == 2) {
+        stream_store(reinterpret_cast<uint32_t *>(dst), w[0]);
+    } else if constexpr (R == 4) {
+        u32x2 v = {w[0], w[1]};
+        stream_store(reinterpret_cast<u32x2 *>(dst), v);
+    } else {
+#pragma unroll
+        for (int q = 0; q < R / 8; q++) {
+            u32x4 v = {w[4 * q + 0], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            stream_store(reinterpret_cast<u32x4 *>(dst) + q, v);
+        }
+    }
+}
+
+/* SW: fold the finished stripe's per-row keys into the lane's best (rows ascend with r and with the stripe index,
+ * so a strict '>' keeps the first row holding the lane's maximum) */
+template <int R, bool LOCAL, bool KEYS>
+__device__ __forceinline__ void lin_fold_keys(const LinState<R, LOCAL> &st, const int row0, const int nrows, int &bestv,
+                                              int &bestrow, int &bestcol) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int hv, col = 0;
+        if constexpr (KEYS) { hv = (int)(st.key[r] >> 16); col = 0xFFFF - (int)(st.key[r] & 0xFFFFu); }
+        else hv = (int)((st.rmaxP[r / 2] >> (16 * (r & 1))) & 0xFFFFu);
+        if (r < nrows && hv > bestv) {
+            bestv = hv;
+            bestrow = row0 + 1 + r;
+            bestcol = col;
+        }
+    }
+}
+
+/* A wave re-reading int16 cells it stored itself.  No fence (an agent-scope release/acquire costs ~1 ms per fill when
+ * 10k waves each issue one): the load bypasses this CU's L1 (`sc1`), is served by the XCD's L2 -- where this wave's
+ * own stores landed, and they are drained first by the caller (`s_waitcnt vmcnt(0)`) -- and is waited for inside
+ * the same asm statement, because hipcc does not count asm loads. */
+__device__ __forceinline__ int load_own_i16(const int16_t *p) {
+    int v;
+    asm volatile("global_load_sshort %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+/* first column of row i (1-based) whose stored score equals `want`; whole wave cooperates; 0 if none */
+template <int R>
+__device__ __forceinline__ int first_col_equal(const int16_t *Hp, size_t cs, int i, int n, int want, int lane) {
+    const int i0 = i - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
+    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + (size_t)l * R + r; /* column 1 */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's stores have reached the L2 */
+    for (int j0 = 1; j0 <= n; j0 += 64) {
+        const int j = j0 + lane;
+        const int v = (j <= n) ? load_own_i16(Hp + rowBase + (size_t)(j - 1) * cs) : -32768;
+        const unsigned long long hit = __ballot(v == want);
+        if (hit) return j0 + __ffsll((long long)hit) - 1;
+    }
+    return 0;
+}
+
+/* WHOLE: store for every lane (the chunk is private to this stripe); otherwise only lanes on a real cell store.
+ * With matrices (STORE) SW tracks packed row maxima, score-only SW tracks (score, column) keys. */
+template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
                                          const bool laneHasRows, const int match, const int mismatch, const int gap,
                                          const int e0, const int rc, int16_t *edge, const bool writeEdge,
@@ -103,39 +210,31 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
     const int upin = wave_shr1(st.Hl[R - 1], e0);
     bool active = true;
     if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
+    uint32_t w[(R + 1) / 2];
     if (active) {
-        int u = upin, d = st.dtop;
-        const unsigned negj = 0xFFFFu - (unsigned)j;
-#if DPX_EXP_NOCOMPUTE /* ablation build only (tools/): stores without the recurrence */
-        st.Hl[0] += u + d + rc + (int)negj;
-#else
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int left = st.Hl[r];
-            const int s = (st.qc[r] == rc) ? match : mismatch;
-            const int g = max(u, left) + gap;
-            int h;
-            if constexpr (LOCAL) h = max(max(g, d + s), 0); /* v_max3_i32 */
-            else h = max(g, d + s);
-            d = left;
-            u = h;
-            st.Hl[r] = h;
-            if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)h << 16) | negj);
-        }
-#endif
-        st.dtop = upin;
+        lin_cells<R, LOCAL, !(STORE && DPX_SW_RESCAN)>(st, upin, rc, j, match, mismatch, gap);
         if (writeEdge && lane == 63) edge[j] = (int16_t)st.Hl[R - 1];
+        if constexpr (STORE) {
+            lin_pack<R, LOCAL, DPX_SW_RESCAN != 0>(st, w);
+            if constexpr (MASKED && !WHOLE) store_words<R>(tileDst, w);
+        }
+    } else if constexpr (STORE) {
+        lin_pack<R, LOCAL, false>(st, w);
     }
     /* Every lane stores, also lanes that are not on a real cell during the skew ramps: the wave then always writes
      * its whole 64*R*2-byte chunk.  Partial chunks (masked stores) measured ~2.5x the cost of full ones -- a chunk
      * with a partly written 64-B sector becomes a read-modify-write at the HBM.  The extra bytes land in the skew
      * padding of the pair's block, which nothing ever reads. */
-    if constexpr (STORE && !(MASKED && DPX_EXP_NORAMPSTORE)) store_tile<R>(tileDst, st.Hl);
+    if constexpr (STORE && (!MASKED || WHOLE) && !(MASKED && DPX_EXP_NORAMPSTORE)) store_words<R>(tileDst, w);
 }
 
 template <int R, bool LOCAL, bool STORE>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    /* How SW finds its start cell (see LinState).  Keys cost 2 VALU ops per cell but nothing afterwards; the packed
+     * row maxima (DPX_SW_RESCAN=1 builds) save 12 ops per step but pay a serial re-read of one matrix row per wave,
+     * which measured 10 % slower on the 10k x 1024^2 batch. */
+    constexpr bool KEYS = !(STORE && DPX_SW_RESCAN);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* wave-uniform: everything per-pair lives in SGPRs */
@@ -163,76 +262,150 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
     for (int x = lane; x <= n + 1; x += 64) edge[x] = (int16_t)(LOCAL ? 0 : x * gap);
 
     int16_t *Hp = a.mat + pr.matOff;
-    const int W = n + 63;
+    const size_t cs = pr.chunkStride;
     const int S = dpx_tiled_stripes(m, R);
 
     int bestv = 0, bestrow = 0, bestcol = 0;
     LinState<R, LOCAL> st;
+#pragma unroll
+    for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
 
-    for (int k = 0; k < S; k++) {
-        const int base = k * 64 * R;
-        const int row0 = base + lane * R; /* rows above the lane's first row */
-        const int nrows = min(max(m - row0, 0), R);
-        const bool laneHasRows = nrows > 0;
-        const bool hasNext = (k + 1 < S);
+    if (STORE && S >= 2 && n >= 128) { /* (score-only fills are VALU-bound: the plain striped loop is leaner there) */
+        /* ---------- rolling schedule: a lane that finishes column n of its stripe starts column 1 of the next one
+         * on the following step, so the skew ramp is paid once per pair instead of once per stripe and every
+         * chunk between the two ramps is a whole one. ---------- */
+        unsigned char *ql = my + a.ldsQryOff; /* staged query: the stripe switch must not wait on global memory */
+        for (int x = lane; x < m; x += 64) ql[x] = qry[x];
+        int row0 = lane * R;
+        int nrows = min(max(m - row0, 0), R);
+        int jl = 1 - lane; /* this lane's column; <= 0: not started yet */
+        int kl = 0;        /* this lane's stripe */
 #pragma unroll
         for (int r = 0; r < R; r++) {
             st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
-            st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
+            st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
             st.key[r] = 0u;
         }
         st.dtop = LOCAL ? 0 : row0 * gap;
-        int16_t *tile = Hp + ((size_t)k * (size_t)W * 64u + (size_t)lane) * R;
-
-        /* software pipeline: the LDS reads of step t+1 (reference character of the lane's next column, and
-         * lane 0's `up` from the edge row) are issued before the arithmetic of step t */
-        const unsigned char *rp = refl + 64 - lane; /* rp[t] = reference character of column j = t - lane + 1 */
-        int rcN = rp[0];
+        int j0 = 1;      /* lane 0's column (wave-uniform): index of its `up` in the edge row */
+        bool sw = false; /* this lane wrapped at the end of the previous step */
+        int rcN = refl[63 + jl];
         int e0N = edge[1];
-#define DPX_LIN_STEP(MASKED_, HASROWS_)                                                                              \
-        {                                                                                                             \
-            const int rc = rcN, e0 = e0N;                                                                             \
-            rcN = rp[t + 1];                                                                                          \
-            e0N = edge[min(t + 2, n + 1)];                                                                            \
-            lin_step<R, LOCAL, STORE, MASKED_>(st, t, lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, hasNext, \
-                                               tile + (size_t)t * 64u * R);                                          \
+        int16_t *tile = Hp + (size_t)lane * R;
+        const int total = S * n + 63;
+        auto roll_step = [&](const int T) {
+            const int rc = rcN, e0 = e0N;
+            const int jn = (jl >= n) ? 1 : jl + 1;
+            rcN = refl[63 + jn];
+            j0 = (j0 >= n) ? 1 : j0 + 1;
+            e0N = edge[j0]; /* read n-64 steps after lane 63 wrote it, 63 steps before lane 63 overwrites it */
+            /* the neighbour's bottom row must be taken BEFORE a switching lane resets its registers */
+            const int upin = wave_shr1(st.Hl[R - 1], e0);
+            if (sw) { /* stripe switch (one lane per step for 64 steps around each stripe boundary) */
+                if constexpr (LOCAL) {
+                    lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
+#pragma unroll
+                    for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
+                }
+                row0 += 64 * R;
+                nrows = min(max(m - row0, 0), R);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    st.qc[r] = (r < nrows) ? (int)ql[row0 + r] : 0x100;
+                    st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+                    st.key[r] = 0u;
+                }
+                st.dtop = LOCAL ? 0 : row0 * gap;
+            }
+            uint32_t w[(R + 1) / 2];
+            if (jl >= 1 && kl < S && nrows > 0) {
+                lin_cells<R, LOCAL, KEYS>(st, upin, rc, jl, match, mismatch, gap);
+                if (lane == 63 && kl + 1 < S) edge[jl] = (int16_t)st.Hl[R - 1];
+                if constexpr (STORE) lin_pack<R, LOCAL, !KEYS>(st, w);
+            } else if constexpr (STORE) {
+                lin_pack<R, LOCAL, false>(st, w);
+            }
+            if constexpr (STORE) store_words<R>(tile + (size_t)T * cs, w); /* whole chunk, every step */
+            sw = false;
+            if (jl >= n) { jl = 1; kl++; sw = kl < S; }
+            else jl++;
+        };
+        int T = 0;
+        for (; T + 1 < total; T += 2) { /* two steps per iteration: lets the register allocator ping-pong the H chain */
+            roll_step(T);
+            roll_step(T + 1);
         }
-        const bool fast = (base + 64 * R <= m) && (n >= 64);
-        if (fast) {
-            int t = 0;
-            for (; t < 63; t++) DPX_LIN_STEP(true, true)
-            for (; t < n; t++) DPX_LIN_STEP(false, true)
-            for (; t < W; t++) DPX_LIN_STEP(true, true)
-        } else {
-            for (int t = 0; t < W; t++) DPX_LIN_STEP(true, laneHasRows)
-        }
-#undef DPX_LIN_STEP
-
-        if constexpr (LOCAL) {
-            /* rows ascend with r and with k: a strict '>' keeps the first row holding the lane's maximum */
+        if (T < total) roll_step(T);
+        if constexpr (LOCAL) lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
+    } else {
+        /* ---------- striped schedule (single stripe, or references too short to roll) ---------- */
+        const int W = n + 63;
+        for (int k = 0; k < S; k++) {
+            const int base = k * 64 * R;
+            const int row0 = base + lane * R; /* rows above the lane's first row */
+            const int nrows = min(max(m - row0, 0), R);
+            const bool laneHasRows = nrows > 0;
+            const bool hasNext = (k + 1 < S);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const int hv = (int)(st.key[r] >> 16);
-                if (r < nrows && hv > bestv) {
-                    bestv = hv;
-                    bestrow = row0 + 1 + r;
-                    bestcol = 0xFFFF - (int)(st.key[r] & 0xFFFFu);
-                }
+                st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+                st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
+                st.key[r] = 0u;
             }
+#pragma unroll
+            for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
+            st.dtop = LOCAL ? 0 : row0 * gap;
+            int16_t *tile = Hp + (size_t)k * (size_t)n * cs + (size_t)lane * R;
+
+            /* software pipeline: the LDS reads of step t+1 (reference character of the lane's next column, and
+             * lane 0's `up` from the edge row) are issued before the arithmetic of step t */
+            const unsigned char *rp = refl + 64 - lane; /* rp[t] = reference character of column j = t - lane + 1 */
+            int rcN = rp[0];
+            int e0N = edge[1];
+#define DPX_LIN_STEP(MASKED_, WHOLE_, HASROWS_)                                                                        \
+            {                                                                                                         \
+                const int rc = rcN, e0 = e0N;                                                                         \
+                rcN = rp[t + 1];                                                                                      \
+                e0N = edge[min(t + 2, n + 1)];                                                                        \
+                lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
+                                                           hasNext, tile + (size_t)t * cs);                          \
+            }
+            const bool fast = (base + 64 * R <= m) && (n >= 64);
+            if (S == 1) { /* the ramp chunks belong to this stripe alone: store them whole */
+                if (fast) {
+                    int t = 0;
+                    for (; t < 63; t++) DPX_LIN_STEP(true, true, true)
+                    for (; t < n; t++) DPX_LIN_STEP(false, true, true)
+                    for (; t < W; t++) DPX_LIN_STEP(true, true, true)
+                } else {
+                    for (int t = 0; t < W; t++) DPX_LIN_STEP(true, true, laneHasRows)
+                }
+            } else { /* several stripes of a short reference share their ramp chunks: masked stores there */
+                for (int t = 0; t < W; t++) DPX_LIN_STEP(true, false, laneHasRows)
+            }
+#undef DPX_LIN_STEP
+            if constexpr (LOCAL) lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
         }
     }
 
     if constexpr (LOCAL) {
         /* first strict maximum in row-major order (c++/LinearSmithWaterman.cpp:145-157):
-         * max score, then smallest row; the lane already holds the smallest column of that row */
+         * max score, then smallest row; then the smallest column of that row */
         const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
         const unsigned long long top = wave_max_u64(mine);
-        if ((int)(top >> 32) == 0) {
+        const int topv = (int)(top >> 32), toprow = 0x7FFFFFFF - (int)(top & 0xFFFFFFFFu);
+        if (topv == 0) {
             if (lane == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
-        } else if (mine == top) { /* rows are unique per lane, so exactly one lane matches */
-            a.score[p] = bestv;
-            a.endRow[p] = bestrow;
-            a.endCol[p] = bestcol;
+        } else if constexpr (KEYS) {
+            if (mine == top) { /* rows are unique per lane, so exactly one lane matches; it holds the row's first column */
+                a.score[p] = bestv;
+                a.endRow[p] = bestrow;
+                a.endCol[p] = bestcol;
+            }
+        } else {
+            /* re-read that one row of the matrix this wave just wrote */
+            const int col = first_col_equal<R>(Hp, cs, toprow, n, topv, lane);
+            if (lane == 0) { a.score[p] = topv; a.endRow[p] = toprow; a.endCol[p] = col; }
         }
     } else {
         /* score = H[m][n] (LinearNeedlemanWunsch.cpp:176): after the last stripe Hl[] holds column n */
@@ -260,12 +433,6 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
  * SW start cell: the loop only keeps a packed per-row running maximum; the (first row, first column) of the maximum
  * is resolved afterwards by re-reading that single row of the matrix this wave just wrote.
  * ===================================================================================================== */
-using dpx::s16x2;
-using dpx::u16x2;
-using dpx::as_s16x2;
-using dpx::as_u16x2;
-using dpx::as_u32;
-
 template <int R>
 struct PkState {
     uint32_t Hl[R];   /* packed H[row][j-1] */
@@ -302,7 +469,7 @@ __device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, cons
     }
 }
 
-template <int R, bool LOCAL, bool MASKED>
+template <int R, bool LOCAL, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                         const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP, const uint32_t e0,
                                         const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB) {
@@ -328,22 +495,9 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
         }
         st.dtop = upin;
         if (writeEdge && lane == 63) edge[j] = st.Hl[R - 1];
+        if constexpr (MASKED && !WHOLE) store_tile_pk<R>(tileA, tileB, st.Hl);
     }
-    store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks, also on the skew ramps (see lin_step) */
-}
-
-/* first column of row i (1-based) whose stored score equals `want`; whole wave cooperates; 0 if none */
-template <int R>
-__device__ __forceinline__ int first_col_equal(const int16_t *Hp, int i, int n, int want, int lane) {
-    const int i0 = i - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
-    const size_t rowBase = (((size_t)k * (size_t)(n + 63) + (size_t)l) * 64u + (size_t)l) * R + r; /* column 1 */
-    for (int j0 = 1; j0 <= n; j0 += 64) {
-        const int j = j0 + lane;
-        const int v = (j <= n) ? (int)Hp[rowBase + (size_t)(j - 1) * 64u * R] : -32768;
-        const unsigned long long hit = __ballot(v == want);
-        if (hit) return j0 + __ffsll((long long)hit) - 1;
-    }
-    return 0;
+    if constexpr (!MASKED || WHOLE) store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks (see lin_step) */
 }
 
 template <int R, bool LOCAL>
@@ -393,28 +547,38 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
             st.rmax[r] = 0u;
         }
         { const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap); st.dtop = ((uint32_t)b << 16) | b; }
-        const size_t tileOff = ((size_t)k * (size_t)W * 64u + (size_t)lane) * R;
-        int16_t *tileA = HpA + tileOff, *tileB = HpB + tileOff;
+        const size_t csA = prA.chunkStride, csB = prB.chunkStride;
+        int16_t *tileA = HpA + (size_t)k * (size_t)n * csA + (size_t)lane * R;
+        int16_t *tileB = HpB + (size_t)k * (size_t)n * csB + (size_t)lane * R;
         const uint16_t *rp = refl + 64 - lane;
         uint32_t rcN = rp[0];
         uint32_t e0N = edge[1];
-#define DPX_PK_STEP(MASKED_, HASROWS_)                                                                                  \
+#define DPX_PK_STEP(MASKED_, WHOLE_, HASROWS_)                                                                                  \
         {                                                                                                             \
             const uint32_t rc16 = rcN, e0 = e0N;                                                                      \
             rcN = rp[t + 1];                                                                                          \
             e0N = edge[min(t + 2, n + 1)];                                                                            \
             const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u); /* {A char, B char} -> 16-bit lanes */  \
-            pk_step<R, LOCAL, MASKED_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext,      \
-                                       tileA + (size_t)t * 64u * R, tileB + (size_t)t * 64u * R);                    \
+            pk_step<R, LOCAL, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext, \
+                                       tileA + (size_t)t * csA, tileB + (size_t)t * csB);                            \
         }
         const bool fast = (base + 64 * R <= m) && (n >= 64);
-        if (fast) {
+        if (S == 1) {
+            if (fast) {
+                int t = 0;
+                for (; t < 63; t++) DPX_PK_STEP(true, true, true)
+                for (; t < n; t++) DPX_PK_STEP(false, true, true)
+                for (; t < W; t++) DPX_PK_STEP(true, true, true)
+            } else {
+                for (int t = 0; t < W; t++) DPX_PK_STEP(true, true, laneHasRows)
+            }
+        } else if (fast) { /* stripes share their ramp chunks: masked stores on the ramps */
             int t = 0;
-            for (; t < 63; t++) DPX_PK_STEP(true, true)
-            for (; t < n; t++) DPX_PK_STEP(false, true)
-            for (; t < W; t++) DPX_PK_STEP(true, true)
+            for (; t < 63; t++) DPX_PK_STEP(true, false, true)
+            for (; t < n; t++) DPX_PK_STEP(false, false, true)
+            for (; t < W; t++) DPX_PK_STEP(true, false, true)
         } else {
-            for (int t = 0; t < W; t++) DPX_PK_STEP(true, laneHasRows)
+            for (int t = 0; t < W; t++) DPX_PK_STEP(true, false, laneHasRows)
         }
 #undef DPX_PK_STEP
         if constexpr (LOCAL) {
@@ -433,10 +597,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         const unsigned long long topB = wave_max_u64(((unsigned long long)(unsigned)bestB << 32) | (unsigned)(0x7FFFFFFF - browB));
         const int mA = (int)(topA >> 32), rA = 0x7FFFFFFF - (int)(topA & 0xFFFFFFFFu);
         const int mB = (int)(topB >> 32), rB = 0x7FFFFFFF - (int)(topB & 0xFFFFFFFFu);
-        /* ... then the first column of that row, re-read from the matrix this wave wrote (stores made visible first) */
-        __threadfence();
-        const int cA = mA > 0 ? first_col_equal<R>(HpA, rA, n, mA, lane) : 0;
-        const int cB = mB > 0 ? first_col_equal<R>(HpB, rB, n, mB, lane) : 0;
+        /* ... then the first column of that row, re-read from the matrix this wave wrote */
+        const int cA = mA > 0 ? first_col_equal<R>(HpA, prA.chunkStride, rA, n, mA, lane) : 0;
+        const int cB = mB > 0 ? first_col_equal<R>(HpB, prB.chunkStride, rB, n, mB, lane) : 0;
         if (lane == 0) {
             a.score[pA] = mA; a.endRow[pA] = mA > 0 ? rA : 0; a.endCol[pA] = cA;
             a.score[pB] = mB; a.endRow[pB] = mB > 0 ? rB : 0; a.endCol[pB] = cB;
@@ -470,7 +633,28 @@ struct AffState {
     int dtop;
 };
 
-template <int R, bool STORE, bool MASKED>
+template <int R>
+__device__ __forceinline__ void aff_cells(AffState<R> &st, const int upH, const int upD, const int rc, const int match,
+                                          const int mismatch, const int oe, const int e) {
+    int uH = upH, uD = upD, d = st.dtop;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int lH = st.Hl[r];
+        const int s = (st.qc[r] == rc) ? match : mismatch;
+        const int Dn = max(uH + oe, uD + e);
+        const int In = max(lH + oe, st.Il[r] + e);
+        const int h = max(max(Dn, d + s), In); /* v_max3_i32 */
+        d = lH;
+        uH = h;
+        uD = Dn;
+        st.Hl[r] = h;
+        st.Il[r] = In;
+        st.Dl[r] = Dn;
+    }
+    st.dtop = upH;
+}
+
+template <int R, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                          const int match, const int mismatch, const int oe, const int e, const int e0H,
                                          const int e0D, const int rc, int16_t *edgeH, int16_t *edgeD,
@@ -481,28 +665,18 @@ __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int
     bool active = true;
     if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
     if (active) {
-        int uH = upH, uD = upD, d = st.dtop;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int lH = st.Hl[r];
-            const int s = (st.qc[r] == rc) ? match : mismatch;
-            const int Dn = max(uH + oe, uD + e);
-            const int In = max(lH + oe, st.Il[r] + e);
-            const int h = max(max(Dn, d + s), In); /* v_max3_i32 */
-            d = lH;
-            uH = h;
-            uD = Dn;
-            st.Hl[r] = h;
-            st.Il[r] = In;
-            st.Dl[r] = Dn;
-        }
-        st.dtop = upH;
+        aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
         if (writeEdge && lane == 63) {
             edgeH[j] = (int16_t)st.Hl[R - 1];
             edgeD[j] = (int16_t)st.Dl[R - 1];
         }
+        if constexpr (STORE && MASKED && !WHOLE) {
+            store_tile<R>(tileDst, st.Hl);
+            store_tile<R>(tileDst + 64 * R, st.Il);
+            store_tile<R>(tileDst + 128 * R, st.Dl);
+        }
     }
-    if constexpr (STORE) { /* whole chunks, also on the skew ramps (see lin_step) */
+    if constexpr (STORE && (!MASKED || WHOLE)) { /* whole chunks, also on the skew ramps (see lin_step) */
         store_tile<R>(tileDst, st.Hl);
         store_tile<R>(tileDst + 64 * R, st.Il);
         store_tile<R>(tileDst + 128 * R, st.Dl);
@@ -546,46 +720,125 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
     const int S = dpx_tiled_stripes(m, R);
     AffState<R> st;
 
-    for (int k = 0; k < S; k++) {
-        const int base = k * 64 * R;
-        const int row0 = base + lane * R;
-        const int nrows = min(max(m - row0, 0), R);
-        const bool laneHasRows = nrows > 0;
-        const bool hasNext = (k + 1 < S);
+    if (STORE && S >= 2 && n >= 128) {
+        /* ---------- rolling schedule (see k_linear_fill): lanes run straight on into the next stripe ---------- */
+        unsigned char *ql = my + a.ldsQryOff;
+        for (int x = lane; x < m; x += 64) ql[x] = qry[x];
+        int row0 = lane * R;
+        int nrows = min(max(m - row0, 0), R);
+        int jl = 1 - lane, kl = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
-            st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (:43-46) */
-            st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
+            st.Hl[r] = o + (row0 + 1 + r) * e;
+            st.Il[r] = DPX_NEG;
             st.Dl[r] = DPX_NEG;
         }
-        st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
-        int16_t *tile = Mp + ((size_t)k * (size_t)W * 3u * 64u + (size_t)lane) * R;
-
-        const unsigned char *rp = refl + 64 - lane;
-        int rcN = rp[0];
+        st.dtop = row0 == 0 ? 0 : o + row0 * e;
+        int j0 = 1;
+        bool sw = false;
+        int rcN = refl[63 + jl];
         int eHN = edgeH[1];
-        int eDN = k == 0 ? DPX_NEG : (int)edgeD[1];
-#define DPX_AFF_STEP(MASKED_, HASROWS_)                                                                               \
-        {                                                                                                             \
-            const int rc = rcN, eH = eHN, eD = eDN;                                                                   \
-            rcN = rp[t + 1];                                                                                          \
-            eHN = edgeH[min(t + 2, n + 1)];                                                                           \
-            eDN = k == 0 ? DPX_NEG : (int)edgeD[min(t + 2, n + 1)];                                                   \
-            aff_step<R, STORE, MASKED_>(st, t, lane, n, HASROWS_, match, mismatch, oe, e, eH, eD, rc, edgeH, edgeD,   \
-                                        hasNext, tile + (size_t)t * 192u * R);                                        \
+        int eDN = DPX_NEG; /* lane 0 is in stripe 0 first: virtual D[0][j] */
+        const size_t cs = pr.chunkStride;
+        int16_t *tile = Mp + (size_t)lane * R;
+        const int total = S * n + 63;
+        auto roll_step = [&](const int T) {
+            const int rc = rcN, eH = eHN, eD = eDN;
+            const int jn = (jl >= n) ? 1 : jl + 1;
+            rcN = refl[63 + jn];
+            j0 = (j0 >= n) ? 1 : j0 + 1;
+            eHN = edgeH[j0];
+            eDN = (T + 1 < n) ? DPX_NEG : (int)edgeD[j0]; /* lane 0 leaves stripe 0 after n steps */
+            const int upH = wave_shr1(st.Hl[R - 1], eH);
+            const int upD = wave_shr1(st.Dl[R - 1], eD);
+            if (sw) {
+                row0 += 64 * R;
+                nrows = min(max(m - row0, 0), R);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    st.qc[r] = (r < nrows) ? (int)ql[row0 + r] : 0x100;
+                    st.Hl[r] = o + (row0 + 1 + r) * e;
+                    st.Il[r] = DPX_NEG;
+                    st.Dl[r] = DPX_NEG;
+                }
+                st.dtop = o + row0 * e;
+            }
+            if (jl >= 1 && kl < S && nrows > 0) {
+                aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
+                if (lane == 63 && kl + 1 < S) {
+                    edgeH[jl] = (int16_t)st.Hl[R - 1];
+                    edgeD[jl] = (int16_t)st.Dl[R - 1];
+                }
+            }
+            if constexpr (STORE) {
+                int16_t *dst = tile + (size_t)T * cs;
+                store_tile<R>(dst, st.Hl);
+                store_tile<R>(dst + 64 * R, st.Il);
+                store_tile<R>(dst + 128 * R, st.Dl);
+            }
+            sw = false;
+            if (jl >= n) { jl = 1; kl++; sw = kl < S; }
+            else jl++;
+        };
+        int T = 0;
+        for (; T + 1 < total; T += 2) {
+            roll_step(T);
+            roll_step(T + 1);
         }
-        const bool fast = (base + 64 * R <= m) && (n >= 64);
-        if (fast) {
-            int t = 0;
-            for (; t < 63; t++) DPX_AFF_STEP(true, true)
-            for (; t < n; t++) DPX_AFF_STEP(false, true)
-            for (; t < W; t++) DPX_AFF_STEP(true, true)
-        } else {
-            for (int t = 0; t < W; t++) DPX_AFF_STEP(true, laneHasRows)
+        if (T < total) roll_step(T);
+    } else {
+    for (int k = 0; k < S; k++) {
+            const int base = k * 64 * R;
+            const int row0 = base + lane * R;
+            const int nrows = min(max(m - row0, 0), R);
+            const bool laneHasRows = nrows > 0;
+            const bool hasNext = (k + 1 < S);
+    #pragma unroll
+            for (int r = 0; r < R; r++) {
+                st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+                st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (:43-46) */
+                st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
+                st.Dl[r] = DPX_NEG;
+            }
+            st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
+            const size_t cs = pr.chunkStride;
+            int16_t *tile = Mp + (size_t)k * (size_t)n * cs + (size_t)lane * R;
+    
+            const unsigned char *rp = refl + 64 - lane;
+            int rcN = rp[0];
+            int eHN = edgeH[1];
+            int eDN = k == 0 ? DPX_NEG : (int)edgeD[1];
+    #define DPX_AFF_STEP(MASKED_, WHOLE_, HASROWS_)                                                                               \
+            {                                                                                                             \
+                const int rc = rcN, eH = eHN, eD = eDN;                                                                   \
+                rcN = rp[t + 1];                                                                                          \
+                eHN = edgeH[min(t + 2, n + 1)];                                                                           \
+                eDN = k == 0 ? DPX_NEG : (int)edgeD[min(t + 2, n + 1)];                                                   \
+                aff_step<R, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, oe, e, eH, eD, rc, edgeH, edgeD, \
+                                            hasNext, tile + (size_t)t * cs);                                              \
+            }
+            const bool fast = (base + 64 * R <= m) && (n >= 64);
+            if (S == 1) {
+                if (fast) {
+                    int t = 0;
+                    for (; t < 63; t++) DPX_AFF_STEP(true, true, true)
+                    for (; t < n; t++) DPX_AFF_STEP(false, true, true)
+                    for (; t < W; t++) DPX_AFF_STEP(true, true, true)
+                } else {
+                    for (int t = 0; t < W; t++) DPX_AFF_STEP(true, true, laneHasRows)
+                }
+            } else if (fast) { /* stripes share their ramp chunks: masked stores on the ramps */
+                int t = 0;
+                for (; t < 63; t++) DPX_AFF_STEP(true, false, true)
+                for (; t < n; t++) DPX_AFF_STEP(false, false, true)
+                for (; t < W; t++) DPX_AFF_STEP(true, false, true)
+            } else {
+                for (int t = 0; t < W; t++) DPX_AFF_STEP(true, false, laneHasRows)
+            }
+    #undef DPX_AFF_STEP
         }
-#undef DPX_AFF_STEP
-    }
+}
     const int lastBase = (S - 1) * 64 * R;
     const int lm = (m - 1 - lastBase) / R, rm = (m - 1 - lastBase) % R;
     if (lane == lm) {
@@ -705,6 +958,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
     const int NS = m + n - 1;               /* anti-diagonals a = 2 .. m+n */
     const int numGroups = (NS + G - 1) / G;
     int16_t *Hp = a.mat + pr.matOff + (size_t)lane * 8u;
+    const size_t cs = pr.chunkStride;
     int acc[8];
     for (int A0 = 0; A0 < NS; A0 += GG) {
         /* parity of step A is (A + B + 1) & 1; A0 is even, so even steps have parity PB and odd steps !PB */
@@ -712,13 +966,13 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
         for (int g = 0; g < GG; g += 2) {
             band_step<C, PB>(st, A0 + g, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);
             if constexpr (STORE && G == 1) {
-                if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * 512u, acc);
+                if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * cs, acc);
             }
             band_step<C, !PB>(st, A0 + g + 1, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[((g + 1) % G) * C]);
             if constexpr (STORE) {
                 if (((g + 1) % G) == G - 1) {
                     const int grp = (A0 + g + 1) / G;
-                    if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * 512u, acc);
+                    if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * cs, acc);
                 }
             }
         }
@@ -769,9 +1023,9 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
             else v = 0;                                              /* LSW / BSW */
         } else if (algo == DPX_K_BSW) {
             const int dlt = i - j;
-            v = (dlt <= band - 1 && -dlt <= band - 1) ? mat[pr.matOff + dpx_band_index(i, j, band)] : 0;
+            v = (dlt <= band - 1 && -dlt <= band - 1) ? mat[pr.matOff + dpx_band_index(i, j, band, pr.chunkStride)] : 0;
         } else {
-            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, planes, plane)];
+            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, plane, pr.chunkStride)];
         }
         out[idx] = (int16_t)v;
     }
@@ -790,6 +1044,7 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
 struct TbView {
     const int16_t *mat;
     uint64_t off;
+    uint32_t cs;
     int n, m, R, planes, algo, band, gapOpen, gapExtend;
     __device__ __forceinline__ int get(int i, int j, int plane) const {
         if (i == 0 || j == 0) { /* closed-form borders, as in k_export_matrix */
@@ -802,9 +1057,9 @@ struct TbView {
         if (algo == DPX_K_BSW) {
             const int dlt = i - j;
             if (dlt > band - 1 || -dlt > band - 1) return 0;
-            return mat[off + dpx_band_index(i, j, band)];
+            return mat[off + dpx_band_index(i, j, band, cs)];
         }
-        return mat[off + dpx_tiled_index(i, j, n, R, planes, plane)];
+        return mat[off + dpx_tiled_index(i, j, n, R, plane, cs)];
     }
 };
 
@@ -820,7 +1075,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
     char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
     int pos = cap; /* lines grow from the back */
     const int match = a.match, mismatch = a.mismatch;
-    TbView v{a.mat, pr.matOff, n, m, R, planes, algo, a.band, a.gapOpen, a.gapExtend};
+    TbView v{a.mat, pr.matOff, pr.chunkStride, n, m, R, planes, algo, a.band, a.gapOpen, a.gapExtend};
 #define EMIT(rc_, xc_, qc_) { --pos; lr[pos] = (char)(rc_); lx[pos] = (char)(xc_); lq[pos] = (char)(qc_); }
     int i = endRow[p], j = endCol[p];
     if (algo == DPX_K_LSW || algo == DPX_K_BSW) {

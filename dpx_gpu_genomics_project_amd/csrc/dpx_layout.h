@@ -3,17 +3,27 @@
  *
  * Full-matrix algorithms (LNW / LSW / ANW): "wavefront-tiled" layout.
  *   One wave owns a pair.  Query rows are cut into stripes of 64*R rows; lane l of the wave owns the R
- *   consecutive rows [l*R, l*R+R) of the stripe and sweeps the columns with a skew of one column per lane
- *   (lane l is on column t-l+1 at step t), so at any step the wave sits on one anti-diagonal of R-row tiles.
- *   What a wave produces in one step is stored contiguously:
+ *   consecutive rows [l*R, l*R+R) of the stripe and sweeps the columns with a skew of one column per lane, and
+ *   rolls straight into the next stripe when it reaches the last column (the reference's V2 idea,
+ *   cuda/LNW/LinearNeedlemanWunschV2.cu:81-148).  Lane l is therefore on stripe k, column j at the pair's step
+ *   T = k*n + (j-1) + l, and what the wave produces in one step is stored contiguously ("chunk" T):
  *
- *       element(i, j, plane) = (((k*W + (j-1) + l) * P + plane) * 64 + l) * R + r
- *       with i0 = i-1, k = i0 / (64R), l = (i0 % (64R)) / R, r = i0 % R, W = n + 63, P = planes (1, or 3 for ANW)
+ *       element(i, j, plane) = ((T * P + plane) * 64 + l) * R + r
+ *       with i0 = i-1, k = i0 / (64R), l = (i0 % (64R)) / R, r = i0 % R, T = k*n + (j-1) + l, P = planes (1; 3 for ANW)
  *
- *   i.e. [stripe][step][plane][lane][row-in-lane] int16.  Every step of a wave is one fully coalesced
- *   64*R*2-byte store per plane (1 KiB at R = 8).  The reference reached the same idea in
- *   cuda/LNW/LinearNeedlemanWunschV17.cu:106-118 (skewed direction matrix, un-skewed by the back-tracker).
+ *   i.e. [step][plane][lane][row-in-lane] int16, S*n + 63 chunks per pair (S = stripes).  Every step of a wave is
+ *   one fully coalesced 64*R*2-byte store per plane (1 KiB at R = 8).  The reference reached the same idea in
+ *   cuda/LNW/LinearNeedlemanWunschV17.cu:106-118 (skewed direction matrix, un-skewed by the back-tracker).  The
+ *   only slots that hold no cell are the 63-step skew ramps at the start and end of a pair (63*64*R*2*P bytes,
+ *   3 % at 1024x1024); they are written (whole chunks are ~2.5x cheaper than partial ones) but never read.
  *   Border row 0 / column 0 are not stored (they are closed-form); dpx_batch_matrix() re-creates them.
+ *
+ *   Group interleaving: G pairs that are launched next to each other (64 by default) share one block in which the
+ *   chunks of the same step lie side by side: chunk T of member g starts at groupBase + (T*G + g)*chunkElems,
+ *   i.e. matOff = groupBase + g*chunkElems and chunkStride = G*chunkElems in the formula above
+ *   (element = matOff + T*chunkStride + (plane*64 + l)*R + r).  The G waves then write one compact, forward-moving
+ *   window instead of G streams 2 MB apart -- measured +12 % write bandwidth (tools/wbench.hip: 5.45 -> 6.12 TB/s),
+ *   the difference between ~7000 and ~200 DRAM pages / TLB entries open at a time.
  *
  * Banded SW: anti-diagonal-major band layout, see dpx_band_index().
  */
@@ -35,22 +45,26 @@
 typedef struct dpx_pair_dev {
     int32_t refIdx, n;  /* reference offset / length  (columns) */
     int32_t qryIdx, m;  /* query offset / length      (rows)    */
-    uint64_t matOff;    /* first int16 element of this pair's matrix block */
+    uint64_t matOff;    /* first int16 element of this pair's chunk 0 */
+    uint32_t chunkStride; /* int16 elements between consecutive chunks (steps) of this pair */
+    uint32_t pad_;
 } dpx_pair_dev;
 
 /* number of stripes / elements of one pair's block */
 DPX_HD int dpx_tiled_stripes(int m, int R) { return (m + 64 * R - 1) / (64 * R); }
-DPX_HD uint64_t dpx_tiled_elems(int m, int n, int R, int planes) {
+DPX_HD uint64_t dpx_tiled_chunks(int m, int n, int R) { /* steps (chunks) of one pair */
     if (m <= 0 || n <= 0) return 0;
-    return (uint64_t)dpx_tiled_stripes(m, R) * (uint64_t)(n + 63) * (uint64_t)planes * 64u * (uint64_t)R;
+    return (uint64_t)dpx_tiled_stripes(m, R) * (uint64_t)n + 63u;
 }
-DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int planes, int plane) {
+DPX_HD uint32_t dpx_tiled_chunk_elems(int R, int planes) { return (uint32_t)(planes * 64 * R); }
+/* offset of cell (i, j) of `plane` relative to the pair's matOff */
+DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride) {
     int i0 = i - 1;
     int k = i0 / (64 * R);
     int l = (i0 % (64 * R)) / R;
     int r = i0 % R;
-    uint64_t T = (uint64_t)k * (uint64_t)(n + 63) + (uint64_t)(j - 1) + (uint64_t)l;
-    return ((T * (uint64_t)planes + (uint64_t)plane) * 64u + (uint64_t)l) * (uint64_t)R + (uint64_t)r;
+    uint64_t T = (uint64_t)k * (uint64_t)n + (uint64_t)(j - 1) + (uint64_t)l;
+    return T * (uint64_t)chunkStride + (uint64_t)((plane * 64 + l) * R + r);
 }
 
 /*
@@ -59,22 +73,23 @@ DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int planes, int plan
  * most B of them exist: slot s = u >> 1 in [0, B).  Lane l holds the C = ceil(B/64) slots [l*C, l*C+C).
  * G = max(1, 8/C) consecutive steps are packed so that every lane writes 16 contiguous bytes:
  *
- *       element(i, j) = ((A/G)*64 + l) * (G*C) + (A%G)*C + c,   A = i+j-2, s = (i-j+B-1)>>1, l = s/C, c = s%C
+ *       element(i, j) = (A/G)*chunkStride + l*(G*C) + (A%G)*C + c,   A = i+j-2, s = (i-j+B-1)>>1, l = s/C, c = s%C
+ *       (chunkStride = 512 elements when a pair stands alone, GROUP*512 when GROUP pairs are interleaved)
  */
 DPX_HD int dpx_band_cpl(int band) { int c = (band + 63) / 64; return c <= 1 ? 1 : c <= 2 ? 2 : c <= 4 ? 4 : 8; } /* cells per lane */
 DPX_HD int dpx_band_group(int C) { return C >= 8 ? 1 : 8 / C; }                                                /* steps per 16-B store */
-DPX_HD uint64_t dpx_band_elems(int m, int n, int band) {
+DPX_HD uint64_t dpx_band_chunks(int m, int n, int band) { /* 512-element (1 KiB) chunks of one pair */
     if (m <= 0 || n <= 0) return 0;
     const int C = dpx_band_cpl(band), G = dpx_band_group(C);
-    const uint64_t groups = ((uint64_t)(m + n - 1) + (uint64_t)G - 1) / (uint64_t)G;
-    return groups * 64u * (uint64_t)(G * C);
+    return ((uint64_t)(m + n - 1) + (uint64_t)G - 1) / (uint64_t)G;
 }
-DPX_HD uint64_t dpx_band_index(int i, int j, int band) {
+/* offset of in-band cell (i, j) relative to the pair's matOff (chunks are group-interleaved like the tiled layout) */
+DPX_HD uint64_t dpx_band_index(int i, int j, int band, uint32_t chunkStride) {
     const int C = dpx_band_cpl(band), G = dpx_band_group(C);
     const int A = i + j - 2;
     const int s = (i - j + (band - 1)) >> 1;
     const int l = s / C, c = s % C;
-    return ((uint64_t)(A / G) * 64u + (uint64_t)l) * (uint64_t)(G * C) + (uint64_t)((A % G) * C + c);
+    return (uint64_t)(A / G) * (uint64_t)chunkStride + (uint64_t)(l * (G * C) + (A % G) * C + c);
 }
 
 #endif
