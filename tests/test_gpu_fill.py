@@ -64,6 +64,20 @@ def test_tile_heights_and_stripe_edges(gpu, algo, w, R, monkeypatch):
         _check_batch(gpu, algo, make_batch(3, m, n, seed=100 + i), w)
 
 
+@pytest.mark.parametrize("R", ["2", "4", "8"])
+@pytest.mark.parametrize("algo,w", [("LSW", (3, -1, -2)), ("LNW", (3, -1, -2)), ("ANW", (3, -1, -3, -1))])
+def test_rolling_schedule_multi_stripe(gpu, algo, w, R, monkeypatch):
+    """References >= 128 columns with 2-4 stripes take the rolling schedule (lanes run on into the next stripe):
+    full and partial last stripes, exact multiples, and a ragged mix that shares one group-interleaved block."""
+    monkeypatch.setenv("DPX_R", R)
+    r = int(R)
+    for i, (m, n) in enumerate([(2 * 64 * r, 128), (3 * 64 * r - 7, 150), (2 * 64 * r + 1, 129), (4 * 64 * r, 131)]):
+        if m * n > 600000:
+            continue
+        _check_batch(gpu, algo, make_batch(3, m, n, seed=200 + i, first_index=95), w)
+    _check_batch(gpu, algo, make_ragged_batch(40, 64 * r + 1, 3 * 64 * r, 128, 200, seed=17), w, check_matrix_every=5)
+
+
 @pytest.mark.parametrize("algo,w", [("LSW", (3, -1, -2)), ("LNW", (3, -1, -2)), ("ANW", (3, -1, -3, -1))])
 def test_ragged_short_reads(gpu, algo, w):
     """cfg1-like ragged batch (reference 100-160, query 80-130) -> exercises the longest-first launch order."""
