@@ -868,9 +868,12 @@ struct BandState {
     int prev[C], prev2[C]; /* anti-diagonals a-1 and a-2 */
     int qch[C], rch[C];    /* query / reference character of each slot's cell */
     unsigned key[C];       /* running max of (H << 16 | 0xFFFF - A): max score, then earliest step */
+    int inBand[2][C];      /* ~0 / 0: is slot s inside the band on a step of parity p (s <= B-1-p)? */
 };
 
-template <int C, bool P1>
+/* INTERIOR: every in-band slot of this anti-diagonal lies inside the matrix, so validity is the per-lane constant
+ * inBand mask (one v_and) instead of two compares against the step's slot window */
+template <int C, bool P1, bool INTERIOR>
 __device__ __forceinline__ void band_step(BandState<C> &st, const int A, const int lane, const int m, const int n, const int B,
                                           const int match, const int mismatch, const int gap, const unsigned char *qL,
                                           const unsigned char *rL, int *out) {
@@ -878,8 +881,8 @@ __device__ __forceinline__ void band_step(BandState<C> &st, const int A, const i
     const int p = P1 ? 1 : 0;
     const int i0 = (a + p - (B - 1)) >> 1; /* row of slot 0 (may be <= 0); a+p-(B-1) is even */
     const int j0 = a - i0;                  /* column of slot 0 */
-    const int smin = max(max(1 - i0, j0 - n), 0);
-    const int smax = min(min(m - i0, j0 - 1), B - 1 - p);
+    const int smin = INTERIOR ? 0 : max(max(1 - i0, j0 - n), 0);
+    const int smax = INTERIOR ? 0 : min(min(m - i0, j0 - 1), B - 1 - p);
     int up[C], left[C];
     if constexpr (P1) {
         const int newq = qL[min(max(i0 + 64 * C - 2, 0), m - 1)];
@@ -903,11 +906,14 @@ __device__ __forceinline__ void band_step(BandState<C> &st, const int A, const i
     const unsigned negA = 0xFFFFu - (unsigned)A;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const int s = lane * C + c;
-        const bool valid = (s >= smin) && (s <= smax);
         const int sc = (st.qch[c] == st.rch[c]) ? match : mismatch;
         int h = max(max(max(up[c], left[c]) + gap, st.prev2[c] + sc), 0);
-        h = valid ? h : 0;
+        if constexpr (INTERIOR) {
+            h &= st.inBand[P1 ? 1 : 0][c];
+        } else {
+            const int s = lane * C + c;
+            h = ((s >= smin) && (s <= smax)) ? h : 0;
+        }
         st.key[c] = max(st.key[c], ((unsigned)h << 16) | negA);
         st.prev2[c] = st.prev[c];
         st.prev[c] = h;
@@ -953,30 +959,41 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
             st.prev[c] = 0;
             st.prev2[c] = 0;
             st.key[c] = 0u;
+            st.inBand[0][c] = (s <= B - 1) ? -1 : 0;
+            st.inBand[1][c] = (s <= B - 2) ? -1 : 0;
         }
     }
+    /* is every in-band slot of anti-diagonal A inside the matrix?  (true for one contiguous range of A) */
+    auto interior = [&](const int A) -> bool {
+        const int aa = A + 2, pp = (aa + B - 1) & 1;
+        const int i0 = (aa + pp - (B - 1)) >> 1, j0 = aa - i0, top = B - 1 - pp;
+        return i0 >= 1 && i0 + top <= m && j0 - top >= 1 && j0 <= n;
+    };
     const int NS = m + n - 1;               /* anti-diagonals a = 2 .. m+n */
     const int numGroups = (NS + G - 1) / G;
     int16_t *Hp = a.mat + pr.matOff + (size_t)lane * 8u;
     const size_t cs = pr.chunkStride;
     int acc[8];
+#define DPX_BAND_BODY(INTERIOR_)                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < GG; g += 2) {                                                                  \
+        band_step<C, PB, INTERIOR_>(st, A0 + g, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);          \
+        if constexpr (STORE && G == 1) {                                                                                  \
+            if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * cs, acc);                                      \
+        }                                                                                                                 \
+        band_step<C, !PB, INTERIOR_>(st, A0 + g + 1, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[((g + 1) % G) * C]); \
+        if constexpr (STORE) {                                                                                            \
+            if (((g + 1) % G) == G - 1) {                                                                                 \
+                const int grp = (A0 + g + 1) / G;                                                                         \
+                if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * cs, acc);                                          \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
     for (int A0 = 0; A0 < NS; A0 += GG) {
         /* parity of step A is (A + B + 1) & 1; A0 is even, so even steps have parity PB and odd steps !PB */
-#pragma unroll
-        for (int g = 0; g < GG; g += 2) {
-            band_step<C, PB>(st, A0 + g, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);
-            if constexpr (STORE && G == 1) {
-                if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * cs, acc);
-            }
-            band_step<C, !PB>(st, A0 + g + 1, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[((g + 1) % G) * C]);
-            if constexpr (STORE) {
-                if (((g + 1) % G) == G - 1) {
-                    const int grp = (A0 + g + 1) / G;
-                    if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * cs, acc);
-                }
-            }
-        }
+        if (interior(A0) && interior(A0 + GG - 1)) { DPX_BAND_BODY(true) }
+        else { DPX_BAND_BODY(false) }
     }
+#undef DPX_BAND_BODY
     /* candidates: every slot's first maximum; rows/cols recovered from (step, slot).  Within a slot cells arrive in
      * row-major order, so the earliest step is the slot's first maximum; across slots pick max score, min row, min col */
     unsigned long long mine = 0ull;
