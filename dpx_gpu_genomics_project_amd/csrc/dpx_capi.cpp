@@ -48,6 +48,75 @@ int bind_device() {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* The matrix pool is by far the largest allocation (22 GB for the headline batch) and hipMalloc/hipFree of that size
+ * cost 50-1000 ms -- the "memory management" slice that dominated the reference's V12 profile (187 of 440 ms) and that
+ * it attacked by pooling (V9) and sizing once (V14).  Batched drivers create same-sized batches back to back, so the
+ * most recently released pool is parked here and handed to the next batch that fits. */
+struct PoolCache {
+    std::mutex mu;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+} g_pool;
+
+hipError_t pool_alloc(void **out, size_t bytes, size_t *actual) {
+    *actual = bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (g_pool.ptr && g_pool.device == g_device && g_pool.bytes >= bytes && g_pool.bytes <= bytes + bytes / 2 + (1u << 20)) {
+            *out = g_pool.ptr;
+            *actual = g_pool.bytes;
+            g_pool.ptr = nullptr;
+            g_pool.bytes = 0;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) { /* give the parked pool back and retry once */
+        void *stale = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_pool.mu);
+            stale = g_pool.ptr;
+            g_pool.ptr = nullptr;
+            g_pool.bytes = 0;
+        }
+        if (stale) {
+            (void)hipGetLastError();
+            (void)hipFree(stale);
+            e = hipMalloc(out, bytes);
+        }
+    }
+    return e;
+}
+
+void pool_release(void *ptr, size_t bytes) {
+    if (!ptr) return;
+    void *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (bytes >= (64u << 20) && g_device >= 0) { /* only large pools are worth parking */
+            evict = g_pool.ptr;
+            g_pool.ptr = ptr;
+            g_pool.bytes = bytes;
+            g_pool.device = g_device;
+        } else {
+            evict = ptr;
+        }
+    }
+    if (evict) (void)hipFree(evict);
+}
+
+void pool_trim() {
+    void *stale = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        stale = g_pool.ptr;
+        g_pool.ptr = nullptr;
+        g_pool.bytes = 0;
+    }
+    if (stale) (void)hipFree(stale);
+}
+
 } // namespace
 
 struct dpx_batch {
@@ -60,6 +129,7 @@ struct dpx_batch {
     bool store = true;
     bool filled = false;
     uint64_t cells = 0, matElems = 0, algBytes = 0, bandCells = 0;
+    size_t matPoolBytes = 0; /* bytes of the block behind dMat (may exceed matElems*2 when a parked pool was reused) */
     int maxN = 0, maxM = 0;
     std::vector<dpx_pair_dev> pairs; /* host mirror of the device pair table */
     char *dSeq = nullptr;
@@ -144,6 +214,7 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
 }
 
 int dpx_shutdown(void) {
+    pool_trim();
     std::lock_guard<std::mutex> lk(g_mu);
     g_device = -1;
     return DPX_OK;
@@ -181,7 +252,7 @@ int dpx_batch_destroy(dpx_batch *b) {
     (void)hipFree(b->dPairs);
     (void)hipFree(b->dOrder);
     (void)hipFree(b->dCouples);
-    (void)hipFree(b->dMat);
+    pool_release(b->dMat, b->matPoolBytes);
     (void)hipFree(b->dScore);
     (void)hipFree(b->dEndRow);
     (void)hipFree(b->dEndCol);
@@ -382,7 +453,11 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->matElems = off;
     }
     if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
-    if (b->store && b->matElems) CREATE_TRY(hipMalloc((void **)&b->dMat, b->matElems * sizeof(int16_t)));
+    if (b->store && b->matElems) {
+        void *pool = nullptr;
+        CREATE_TRY(pool_alloc(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
+        b->dMat = (int16_t *)pool;
+    }
 #undef CREATE_TRY
 
     dpx_fill_args &a = b->args;
