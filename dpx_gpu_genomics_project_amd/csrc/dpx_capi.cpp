@@ -353,6 +353,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 16, 16); /* staged query of the rolling multi-stripe schedule */
     const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes + rollQ;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
+    if (const char *env = getenv("DPX_LDS_PAD")) b->ldsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 
 #define CREATE_TRY(call)                                                      \
@@ -490,11 +491,20 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
 }
 
 static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
+    const bool sw = b->kernelAlgo == DPX_ALGO_LSW && b->store;
     if (b->packed) {
         hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
         if (e != hipSuccess) return e;
+        if (sw) { /* both members of every couple need their start column */
+            dpx_fill_args loc = b->pkArgs;
+            loc.numPairs = b->pkArgs.numPairs * 2;
+            e = dpx_launch_sw_locate(loc, b->R, s);
+            if (e != hipSuccess) return e;
+        }
     }
-    return dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
+    hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
+    if (e == hipSuccess && sw && DPX_SW_RESCAN) e = dpx_launch_sw_locate(b->args, b->R, s);
+    return e;
 }
 
 int dpx_batch_fill(dpx_batch *b, void *stream) {

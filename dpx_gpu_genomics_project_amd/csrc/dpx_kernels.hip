@@ -47,9 +47,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DPX_EXP_NORAMPSTORE
 #define DPX_EXP_NORAMPSTORE 0
 #endif
-#ifndef DPX_SW_RESCAN
-#define DPX_SW_RESCAN 0
-#endif
+
 template <class V>
 __device__ __forceinline__ void stream_store(V *dst, V v) {
 #if DPX_NT_STORES
@@ -198,6 +196,41 @@ __device__ __forceinline__ int first_col_equal(const int16_t *Hp, size_t cs, int
     return 0;
 }
 
+/* SW start-cell completion.  The fill kernels that track packed row maxima know the maximum and its first row when
+ * they finish, but not its first column; this follow-up launch (one wave per pair, same stream) reads that single row
+ * back -- 2 bytes x n per pair -- and fills in endCol.  Doing the re-read inside the fill wave instead costs 10 %: the
+ * wave must first drain its own stores and then sits on its SIMD slot through a chain of dependent loads. */
+template <int R>
+__global__ void __launch_bounds__(256) k_sw_locate(const dpx_fill_args a) {
+    const int lane = threadIdx.x & 63;
+    int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (p >= a.numPairs) return;
+    if (a.order) p = a.order[p];
+    const int want = a.score[p], row = a.endRow[p];
+    if (want <= 0 || row <= 0) return; /* score 0: (0, 0) already written */
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, i0 = row - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
+    const int16_t *Hp = a.mat + pr.matOff;
+    const size_t cs = pr.chunkStride;
+    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + (size_t)l * R + r; /* column 1 */
+    for (int j0 = 1; j0 <= n; j0 += 256) { /* four independent loads in flight per lane */
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = j0 + 64 * q + lane;
+            v[q] = (j <= n) ? (int)Hp[rowBase + (size_t)(j - 1) * cs] : -32768;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long hit = __ballot(v[q] == want);
+            if (hit) {
+                if (lane == 0) a.endCol[p] = j0 + 64 * q + __ffsll((long long)hit) - 1;
+                return;
+            }
+        }
+    }
+}
+
 /* WHOLE: store for every lane (the chunk is private to this stripe); otherwise only lanes on a real cell store.
  * With matrices (STORE) SW tracks packed row maxima, score-only SW tracks (score, column) keys. */
 template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
@@ -231,9 +264,9 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
 template <int R, bool LOCAL, bool STORE>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    /* How SW finds its start cell (see LinState).  Keys cost 2 VALU ops per cell but nothing afterwards; the packed
-     * row maxima (DPX_SW_RESCAN=1 builds) save 12 ops per step but pay a serial re-read of one matrix row per wave,
-     * which measured 10 % slower on the 10k x 1024^2 batch. */
+    /* How SW finds its start cell (see LinState): score-only fills track (score, column) keys (2 VALU ops per cell);
+     * fills that write the matrix track packed row maxima (12 fewer ops per step at R = 8) and k_sw_locate re-reads
+     * the winning row afterwards. */
     constexpr bool KEYS = !(STORE && DPX_SW_RESCAN);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,9 +436,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 a.endCol[p] = bestcol;
             }
         } else {
-            /* re-read that one row of the matrix this wave just wrote */
-            const int col = first_col_equal<R>(Hp, cs, toprow, n, topv, lane);
-            if (lane == 0) { a.score[p] = topv; a.endRow[p] = toprow; a.endCol[p] = col; }
+            if (lane == 0) { a.score[p] = topv; a.endRow[p] = toprow; a.endCol[p] = 0; } /* column: k_sw_locate */
         }
     } else {
         /* score = H[m][n] (LinearNeedlemanWunsch.cpp:176): after the last stripe Hl[] holds column n */
@@ -597,12 +628,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         const unsigned long long topB = wave_max_u64(((unsigned long long)(unsigned)bestB << 32) | (unsigned)(0x7FFFFFFF - browB));
         const int mA = (int)(topA >> 32), rA = 0x7FFFFFFF - (int)(topA & 0xFFFFFFFFu);
         const int mB = (int)(topB >> 32), rB = 0x7FFFFFFF - (int)(topB & 0xFFFFFFFFu);
-        /* ... then the first column of that row, re-read from the matrix this wave wrote */
-        const int cA = mA > 0 ? first_col_equal<R>(HpA, prA.chunkStride, rA, n, mA, lane) : 0;
-        const int cB = mB > 0 ? first_col_equal<R>(HpB, prB.chunkStride, rB, n, mB, lane) : 0;
+        /* ... the first column of that row is filled in by k_sw_locate */
         if (lane == 0) {
-            a.score[pA] = mA; a.endRow[pA] = mA > 0 ? rA : 0; a.endCol[pA] = cA;
-            a.score[pB] = mB; a.endRow[pB] = mB > 0 ? rB : 0; a.endCol[pB] = cB;
+            a.score[pA] = mA; a.endRow[pA] = mA > 0 ? rA : 0; a.endCol[pA] = 0;
+            a.score[pB] = mB; a.endRow[pB] = mB > 0 ? rB : 0; a.endCol[pB] = 0;
         }
     } else {
         const int lastBase = (S - 1) * 64 * R;
@@ -1291,6 +1320,20 @@ hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_
     case 16: return launch_linear_pk_R<16>(a, local, grid, ldsBytes, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+/* SW start-cell completion for pairs filled by a row-maxima kernel; a.order / a.numPairs select the pairs */
+hipError_t dpx_launch_sw_locate(const dpx_fill_args &a, int R, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    dim3 grid((unsigned)((a.numPairs + 3) / 4));
+    switch (R) {
+    case 2: hipLaunchKernelGGL(k_sw_locate<2>, grid, dim3(256), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(k_sw_locate<4>, grid, dim3(256), 0, stream, a); break;
+    case 8: hipLaunchKernelGGL(k_sw_locate<8>, grid, dim3(256), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL(k_sw_locate<16>, grid, dim3(256), 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
