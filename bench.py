@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4000, help="pairs of the CPU-baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default). gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only; RCCL refuses this)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,11 +124,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dpx.init(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     algo_name, npairs, m, n, match, mismatch, gap_open, gap_extend, seed = WORKLOADS[args.workload]
     if args.pairs:
@@ -145,10 +153,15 @@ def main():
     scores_t = torch.as_tensor(_DevArray(d_scores, npairs), device=torch.device("cuda", local_rank))
     from dpx_gpu_genomics_project_amd.shard import gather_scores
 
+    def exchange():
+        if args.backend == "nccl":
+            return gather_scores(scores_t, rank, world)  # RCCL over xGMI: 4 B x pairs per rank
+        return gather_scores(scores_t.cpu(), rank, world)  # gloo rehearsal: host tensors
+
     def step():
         batch.fill(stream)  # async launch on torch's current stream
         if world > 1:
-            return gather_scores(scores_t, rank, world)  # RCCL over xGMI: 4 B x pairs per rank
+            return exchange()
 
     def fence():
         if world > 1:
@@ -165,13 +178,14 @@ def main():
         batch.fill(stream)
         ev[k][1].record()
         if world > 1:
-            gather_scores(scores_t, rank, world)
+            last = exchange()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=scores_t.device)
-    kt = torch.tensor([kernel_ms], dtype=torch.float64, device=scores_t.device)
+    red_dev = scores_t.device if args.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    kt = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
@@ -181,8 +195,10 @@ def main():
     scores, er, ec = batch.results()
     ident = [p for p in range(npairs) if (rank * npairs + p) % 101 == 100][:4]
     for p in ident:
-        if algo_name == "ANW" or algo_name == "LNW" or algo_name == "LSW" or algo_name == "BSW":
-            assert scores[p] == match * min(m, n), "identical pair must score match*len"
+        assert scores[p] == match * min(m, n), "identical pair must score match*len"
+    if world > 1 and rank == 0:  # the gathered vector must carry every rank's scores in rank order
+        assert last is not None and last.numel() == npairs * world
+        assert torch.equal(last[:npairs].cpu(), torch.from_numpy(scores))
 
     if rank == 0:
         total_cells = info["cells"] * world

@@ -353,6 +353,9 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 16, 16); /* staged query of the rolling multi-stripe schedule */
     const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes + rollQ;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
+    /* Store-bound fills run ~2 % faster with 3-4 waves per SIMD than with 6-7 (fewer write streams in flight,
+     * profiles/README.md): cap residency at 4 workgroups per CU through the LDS request. */
+    if (b->store && !banded && b->ldsBytes < 36u * 1024u) b->ldsBytes = 36u * 1024u;
     if (const char *env = getenv("DPX_LDS_PAD")) b->ldsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 

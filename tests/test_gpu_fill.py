@@ -122,3 +122,18 @@ def test_int16_range_is_enforced(gpu):
     with pytest.raises(gpu.DpxError) as e:
         gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, 1000, -1, -2)
     assert e.value.status == -4
+
+
+@pytest.mark.parametrize("algo,w", [("LSW", (3, -1, -2)), ("ANW", (3, -1, -3, -1))])
+def test_long_reads_4096_need_more_than_64k_lds(gpu, algo, w):
+    """4096x4096 pairs: the workgroup's dynamic LDS request exceeds the 64 KiB default (hipFuncSetAttribute path),
+    8 stripes roll into each other, and scores approach the int16 ceiling (identical pair: 12288)."""
+    sb = make_batch(2, 4096, 4096, seed=41, first_index=100)   # pair 0 identical, pair 1 mutated
+    _check_batch(gpu, algo, sb, w)
+
+
+def test_sequences_too_long_for_lds_are_refused(gpu):
+    sb = make_batch(1, 10000, 10000, seed=1)
+    with pytest.raises(gpu.DpxError) as e:
+        gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, 3, -1, -2)
+    assert e.value.status == -8   # DPX_ERR_UNSUPPORTED, never a silent fallback
