@@ -229,19 +229,26 @@ static int validate_params(const dpx_params *p) {
     return DPX_OK;
 }
 
-/* Can every value the algorithm stores for an (m x n) pair be held in an int16 cell? */
+/* Can every value the algorithm stores for an (m x n) pair be held in an int16 cell?  Rigorous bounds: every H cell is
+ * the maximum over alignment paths, so it is >= the score of the all-gap path and <= the sum of the positive
+ * contributions any path can collect; the affine gap matrices are one open/extension away from an H cell. */
 static bool fits_int16(const dpx_params &p, long long m, long long n) {
-    auto ab = [](long long v) { return v < 0 ? -v : v; };
-    const long long lim = 32767;
+    auto pos = [](long long v) { return v > 0 ? v : 0; };
+    auto neg = [](long long v) { return v < 0 ? v : 0; };
+    const long long lim = 32767, diag = pos(std::max<long long>(p.match, p.mismatch)) * std::min(m, n);
     if (p.algo == DPX_ALGO_LSW || p.algo == DPX_ALGO_BSW) {
-        /* 0 <= H <= max(match,0) * min(m,n); the kernel also packs the column into 16 bits */
-        long long top = std::max<long long>(p.match, 0) * std::min(m, n);
+        /* 0 <= H <= best diagonal run (+ positive gaps); the kernels also pack a column / step index into 16 bits */
+        const long long top = diag + pos(p.gapOpen) * (m + n);
         return top <= lim && n <= 65000 && (m + n) <= 65000;
     }
-    long long w = std::max({ab(p.match), ab(p.mismatch), ab(p.gapOpen)});
-    if (p.algo == DPX_ALGO_LNW) return (m + n) * w <= lim;
-    w = std::max({w, ab(p.gapExtend), ab((long long)p.gapOpen + p.gapExtend)});
-    return ab(p.gapOpen) + (m + n + 1) * w <= lim;
+    if (p.algo == DPX_ALGO_LNW) {
+        const long long lo = neg(p.gapOpen) * (m + n), hi = diag + pos(p.gapOpen) * (m + n);
+        return lo >= -lim && hi <= lim;
+    }
+    const long long o = p.gapOpen, e = p.gapExtend;
+    const long long loH = 2 * neg(o) + neg(e) * (m + n), hiH = diag + (pos(o) + pos(e)) * (m + n);
+    const long long lo = loH + neg(o + e), hi = hiH + pos(o) + pos(e) * std::max(m, n);
+    return lo >= -lim && hi <= lim;
 }
 
 int dpx_batch_destroy(dpx_batch *b) {
