@@ -98,7 +98,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="lsw_10k_1024", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

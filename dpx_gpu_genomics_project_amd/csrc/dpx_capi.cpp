@@ -310,7 +310,9 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     }
 
     /* rows per lane: smallest tile that keeps short queries in one stripe, 8 (or DPX_R) otherwise */
-    int R = b->maxM <= 128 ? 2 : b->maxM <= 256 ? 4 : 8;
+    /* linear gaps: 16 rows per lane once a query is longer than 512 (one stripe up to 1024 rows, two 1-KiB sub-tiles per
+     * step: measured 4 % faster than 8 rows x 2 rolling stripes); the affine kernel carries three chains and stays at 8 */
+    int R = b->maxM <= 128 ? 2 : b->maxM <= 256 ? 4 : (b->maxM <= 512 || params->algo == DPX_ALGO_ANW) ? 8 : 16;
     if (const char *env = getenv("DPX_R")) {
         int v = atoi(env);
         if (v == 2 || v == 4 || v == 8 || (v == 16 && params->algo != DPX_ALGO_ANW)) R = v;

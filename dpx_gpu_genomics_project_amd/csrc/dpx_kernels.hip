@@ -71,7 +71,7 @@ __device__ __forceinline__ void store_tile(int16_t *dst, const int (&v)[R]) {
         for (int q = 0; q < R / 8; q++) {
             u32x4 w = {pack_lo16(v[8 * q + 0], v[8 * q + 1]), pack_lo16(v[8 * q + 2], v[8 * q + 3]),
                        pack_lo16(v[8 * q + 4], v[8 * q + 5]), pack_lo16(v[8 * q + 6], v[8 * q + 7])};
-            stream_store(reinterpret_cast<u32x4 *>(dst) + q, w);
+            stream_store(reinterpret_cast<u32x4 *>(dst + q * 512), w); /* sub-tile q: its own 1 KiB [lane][8] block */
         }
     }
 }
@@ -148,7 +148,7 @@ __device__ __forceinline__ void store_words(int16_t *dst, const uint32_t (&w)[(R
 #pragma unroll
         for (int q = 0; q < R / 8; q++) {
             u32x4 v = {w[4 * q + 0], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-            stream_store(reinterpret_cast<u32x4 *>(dst) + q, v);
+            stream_store(reinterpret_cast<u32x4 *>(dst + q * 512), v); /* sub-tile q: its own 1 KiB [lane][8] block */
         }
     }
 }
@@ -185,7 +185,7 @@ __device__ __forceinline__ int load_own_i16(const int16_t *p) {
 template <int R>
 __device__ __forceinline__ int first_col_equal(const int16_t *Hp, size_t cs, int i, int n, int want, int lane) {
     const int i0 = i - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
-    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + (size_t)l * R + r; /* column 1 */
+    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + dpx_tile_off(R, 0, l, r); /* column 1 */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's stores have reached the L2 */
     for (int j0 = 1; j0 <= n; j0 += 64) {
         const int j = j0 + lane;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_sw_locate(const dpx_fill_args a) {
     const int n = pr.n, i0 = row - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
     const int16_t *Hp = a.mat + pr.matOff;
     const size_t cs = pr.chunkStride;
-    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + (size_t)l * R + r; /* column 1 */
+    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + dpx_tile_off(R, 0, l, r); /* column 1 */
     for (int j0 = 1; j0 <= n; j0 += 256) { /* four independent loads in flight per lane */
         int v[4];
 #pragma unroll
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
         bool sw = false; /* this lane wrapped at the end of the previous step */
         int rcN = refl[63 + jl];
         int e0N = edge[1];
-        int16_t *tile = Hp + (size_t)lane * R;
+        int16_t *tile = Hp + (size_t)lane * (R < 8 ? R : 8);
         const int total = S * n + 63;
         auto roll_step = [&](const int T) {
             const int rc = rcN, e0 = e0N;
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
 #pragma unroll
             for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
             st.dtop = LOCAL ? 0 : row0 * gap;
-            int16_t *tile = Hp + (size_t)k * (size_t)n * cs + (size_t)lane * R;
+            int16_t *tile = Hp + (size_t)k * (size_t)n * cs + (size_t)lane * (R < 8 ? R : 8);
 
             /* software pipeline: the LDS reads of step t+1 (reference character of the lane's next column, and
              * lane 0's `up` from the edge row) are issued before the arithmetic of step t */
@@ -494,8 +494,8 @@ __device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, cons
             a.z = pk_hi16(v[8 * q + 4], v[8 * q + 5]); a.w = pk_hi16(v[8 * q + 6], v[8 * q + 7]);
             b.x = pack_lo16((int)v[8 * q + 0], (int)v[8 * q + 1]); b.y = pack_lo16((int)v[8 * q + 2], (int)v[8 * q + 3]);
             b.z = pack_lo16((int)v[8 * q + 4], (int)v[8 * q + 5]); b.w = pack_lo16((int)v[8 * q + 6], (int)v[8 * q + 7]);
-            reinterpret_cast<uint4 *>(dstA)[q] = a;
-            reinterpret_cast<uint4 *>(dstB)[q] = b;
+            *reinterpret_cast<uint4 *>(dstA + q * 512) = a; /* sub-tile q */
+            *reinterpret_cast<uint4 *>(dstB + q * 512) = b;
         }
     }
 }
@@ -579,8 +579,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         }
         { const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap); st.dtop = ((uint32_t)b << 16) | b; }
         const size_t csA = prA.chunkStride, csB = prB.chunkStride;
-        int16_t *tileA = HpA + (size_t)k * (size_t)n * csA + (size_t)lane * R;
-        int16_t *tileB = HpB + (size_t)k * (size_t)n * csB + (size_t)lane * R;
+        int16_t *tileA = HpA + (size_t)k * (size_t)n * csA + (size_t)lane * (R < 8 ? R : 8);
+        int16_t *tileB = HpB + (size_t)k * (size_t)n * csB + (size_t)lane * (R < 8 ? R : 8);
         const uint16_t *rp = refl + 64 - lane;
         uint32_t rcN = rp[0];
         uint32_t e0N = edge[1];

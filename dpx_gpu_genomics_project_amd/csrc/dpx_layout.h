@@ -8,7 +8,7 @@
  *   cuda/LNW/LinearNeedlemanWunschV2.cu:81-148).  Lane l is therefore on stripe k, column j at the pair's step
  *   T = k*n + (j-1) + l, and what the wave produces in one step is stored contiguously ("chunk" T):
  *
- *       element(i, j, plane) = ((T * P + plane) * 64 + l) * R + r
+ *       element(i, j, plane) = matOff + T * chunkStride + (plane * 64 + l) * R + r      (R <= 8; R = 16: dpx_tile_off)
  *       with i0 = i-1, k = i0 / (64R), l = (i0 % (64R)) / R, r = i0 % R, T = k*n + (j-1) + l, P = planes (1; 3 for ANW)
  *
  *   i.e. [step][plane][lane][row-in-lane] int16, S*n + 63 chunks per pair (S = stripes).  Every step of a wave is
@@ -57,6 +57,13 @@ DPX_HD uint64_t dpx_tiled_chunks(int m, int n, int R) { /* steps (chunks) of one
     return (uint64_t)dpx_tiled_stripes(m, R) * (uint64_t)n + 63u;
 }
 DPX_HD uint32_t dpx_tiled_chunk_elems(int R, int planes) { return (uint32_t)(planes * 64 * R); }
+/* Position of (plane, lane l, row-in-lane r) inside a chunk.  A lane's rows are kept in sub-tiles of at most 8 rows
+ * (16 B per lane), each sub-tile a contiguous 1 KiB [lane][8] block, so every store instruction of the wave covers
+ * whole 64-B sectors: for R = 16 the chunk is [plane][sub-tile 0..1][lane][8] instead of [plane][lane][16]. */
+DPX_HD uint32_t dpx_tile_off(int R, int plane, int l, int r) {
+    const int Rq = R < 8 ? R : 8, Q = R / Rq;
+    return (uint32_t)(((plane * Q + r / Rq) * 64 + l) * Rq + r % Rq);
+}
 /* offset of cell (i, j) of `plane` relative to the pair's matOff */
 DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride) {
     int i0 = i - 1;
@@ -64,7 +71,7 @@ DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t 
     int l = (i0 % (64 * R)) / R;
     int r = i0 % R;
     uint64_t T = (uint64_t)k * (uint64_t)n + (uint64_t)(j - 1) + (uint64_t)l;
-    return T * (uint64_t)chunkStride + (uint64_t)((plane * 64 + l) * R + r);
+    return T * (uint64_t)chunkStride + (uint64_t)dpx_tile_off(R, plane, l, r);
 }
 
 /*
