@@ -142,6 +142,8 @@ struct dpx_batch {
     dpx_fill_args args{};
     size_t ldsBytes = 0;
     /* packed two-pairs-per-wave path (LNW/LSW with matrices): couples of equal-shaped pairs + leftover singles */
+    bool streamed = false; /* uniform batch on the stream schedule (k_linear_stream) */
+    size_t streamLds = 0;
     bool packed = false;
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
@@ -383,11 +385,12 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
     /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
     std::vector<int32_t> singles, couples;
-    /* "+Opt" packed path: parity-green, but on MI355X it measured 5-10 % slower than one pair per wave because the fill is
-     * bound by HBM stores, not VALU (profiles/README.md) -- opt-in with DPX_PACKED=1 */
-    bool usePacked = false;
-    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0;
-    usePacked = usePacked && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
+    /* "+Opt" packed path (two equal-shaped pairs per wave on the v_pk_*_i16 pipe).  The fill is bound by store
+     * instructions per CU-cycle, so halving the VALU work buys no cycles -- it buys clock: the chip holds ~2.3 GHz
+     * instead of ~2.1 GHz under the lighter instruction stream (profiles/README.md), 4-7 % wall time.  Used when every
+     * query fits one stripe (the packed kernel has no rolling schedule); DPX_PACKED=0/1 overrides. */
+    bool usePacked = b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) && dpx_tiled_stripes(b->maxM, b->R) == 1;
+    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
     if (usePacked) {
         std::vector<int32_t> idx;
         idx.reserve(numPairs);
@@ -432,6 +435,34 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const size_t numSingles = b->packed ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
+    /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
+    int numStreams = 0;
+    {
+        bool want = b->store && !b->packed && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
+                    b->pairs[0].m > 0 && b->pairs[0].n >= 128;
+        /* opt-in: bit-exact and 3 % fewer bytes written, but not faster than one launch-scheduled wave per pair -- the
+         * fill is bound by store instructions per CU-cycle either way (profiles/README.md) */
+        want = want && getenv("DPX_STREAM") && atoi(getenv("DPX_STREAM")) != 0;
+        if (want) {
+            hipDeviceProp_t prop;
+            int cus = 256;
+            if (hipGetDeviceProperties(&prop, g_device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            /* One stream per wave slot.  Whole workgroups per CU (the dispatcher deals workgroups round-robin, so CU j gets
+             * blocks j, j+CUs, ...): numStreams = CUs * 4 waves * k workgroups, k <= 4 (the LDS request caps residency at
+             * 4 workgroups per CU).  A ragged multiple (e.g. 3.26 workgroups per CU) measured 24 % slower: the CUs
+             * that get one workgroup more finish last while the others idle. */
+            size_t slots = (size_t)cus * 4;
+            if (const char *env = getenv("DPX_STREAM_RESIDENT")) { const int v = atoi(env); if (v >= 1) slots = (size_t)v; } /* tests */
+            const size_t k = std::min<size_t>(4, (numPairs + slots - 1) / slots);
+            numStreams = (int)std::min(numPairs, slots * k);
+            want = numPairs > (size_t)numStreams || getenv("DPX_STREAM_RESIDENT"); /* only worth it with >= 2 pairs per stream */
+            if (!want) numStreams = 0;
+        }
+        if (want) {
+            b->streamed = true;
+        }
+    }
+
     /* matrix placement (dpx_layout.h): pairs that are launched next to each other are interleaved chunk by chunk in
      * groups of `group` waves, so a group writes one compact moving window instead of `group` far-apart streams */
     if (b->store) {
@@ -455,8 +486,27 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
                 off += maxChunks * (uint64_t)cnt * chunkElems;
             }
         };
-        if (b->packed) place(couples, (size_t)group * 2); /* one wave = two adjacent slots */
-        if (b->packed || !singles.empty()) {
+        if (b->streamed) {
+            /* streams are interleaved in groups like pairs; inside a stream the pairs follow each other S*n chunks apart */
+            const uint64_t pairChunks = dpx_tiled_chunks(b->pairs[0].m, b->pairs[0].n, b->R) - 63u; /* S*n */
+            for (size_t s0 = 0; s0 < (size_t)numStreams; s0 += (size_t)group) {
+                const size_t cntS = std::min((size_t)group, (size_t)numStreams - s0);
+                uint64_t maxPairs = 0;
+                for (size_t g = 0; g < cntS; g++) {
+                    const size_t sidx = s0 + g;
+                    const uint64_t c = (numPairs - sidx + (size_t)numStreams - 1) / (size_t)numStreams;
+                    maxPairs = std::max(maxPairs, c);
+                    for (uint64_t ord = 0; ord < c; ord++) {
+                        dpx_pair_dev &pd = b->pairs[sidx + ord * (size_t)numStreams];
+                        pd.chunkStride = (uint32_t)(cntS * chunkElems);
+                        pd.matOff = off + (uint64_t)g * chunkElems + ord * pairChunks * pd.chunkStride;
+                    }
+                }
+                off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
+            }
+        } else if (b->packed) place(couples, (size_t)group * 2); /* one wave = two adjacent slots */
+        if (b->streamed) {
+        } else if (b->packed || !singles.empty()) {
             place(singles, (size_t)group);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
@@ -486,6 +536,19 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     a.ldsEdge2Off = (uint32_t)edgeBytes;
     a.ldsRefOff = banded ? (uint32_t)qBytes : (uint32_t)(edgeBytes * nEdges);
     a.ldsQryOff = banded ? 0u : (uint32_t)(edgeBytes * nEdges + refBytes);
+    a.numStreams = numStreams;
+    a.uniM = numPairs ? b->pairs[0].m : 0;
+    a.uniN = numPairs ? b->pairs[0].n : 0;
+    a.ldsBufStride = 0;
+    if (b->streamed) { /* per wave: edge row + 2 x (reference [n+128] + query [m + 64R + 16]) */
+        const size_t refB = align_up((size_t)b->maxN + 128, 16), qB = align_up((size_t)b->maxM + 64 * 16 + 16, 16);
+        a.ldsRefOff = (uint32_t)edgeBytes;
+        a.ldsQryOff = (uint32_t)(edgeBytes + refB);
+        a.ldsBufStride = (uint32_t)(refB + qB);
+        a.ldsPerWave = (uint32_t)(edgeBytes + 2 * (refB + qB));
+        b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), 36u * 1024u);
+        if (b->streamLds > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+    }
     if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
         dpx_fill_args &k = b->pkArgs;
         k = a;
@@ -507,13 +570,8 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     if (b->packed) {
         hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
         if (e != hipSuccess) return e;
-        if (sw) { /* both members of every couple need their start column */
-            dpx_fill_args loc = b->pkArgs;
-            loc.numPairs = b->pkArgs.numPairs * 2;
-            e = dpx_launch_sw_locate(loc, b->R, s);
-            if (e != hipSuccess) return e;
-        }
     }
+    if (b->streamed) return dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
     hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
     if (e == hipSuccess && sw && DPX_SW_RESCAN) e = dpx_launch_sw_locate(b->args, b->R, s);
     return e;

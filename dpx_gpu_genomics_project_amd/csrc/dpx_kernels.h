@@ -34,9 +34,13 @@ typedef struct dpx_fill_args {
     uint32_t ldsEdge2Off;       /* ANW: offset of the second edge row (D) */
     uint32_t ldsRefOff;         /* offset of the staged reference characters */
     uint32_t ldsQryOff;         /* offset of the staged query characters (rolling multi-stripe path) */
+    /* stream schedule (uniform batches): wave s of numStreams fills pairs s, s+numStreams, ... back to back */
+    int32_t numStreams, uniM, uniN;
+    uint32_t ldsBufStride;      /* bytes between the two staged (reference, query) buffers */
 } dpx_fill_args;
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
+hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_sw_locate(const dpx_fill_args &a, int R, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,

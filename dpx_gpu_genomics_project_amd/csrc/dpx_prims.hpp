@@ -118,6 +118,22 @@ __device__ __forceinline__ uint32_t pk_mad_i16_raw(uint32_t a, uint32_t b, uint3
     return r;
 }
 
+__device__ __forceinline__ uint32_t pk_sub_u16_raw(uint32_t a, uint32_t b) { /* per half: a - b (wraps) */
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16_raw(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfi_b32(uint32_t mask, uint32_t a, uint32_t b) { /* (mask & a) | (~mask & b) */
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 /* pack the low halves of two ints into one dword: one v_perm_b32 */
 __device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
