@@ -389,7 +389,8 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
      * instructions per CU-cycle, so halving the VALU work buys no cycles -- it buys clock: the chip holds ~2.3 GHz
      * instead of ~2.1 GHz under the lighter instruction stream (profiles/README.md), 4-7 % wall time.  Used when every
      * query fits one stripe (the packed kernel has no rolling schedule); DPX_PACKED=0/1 overrides. */
-    bool usePacked = b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) && dpx_tiled_stripes(b->maxM, b->R) == 1;
+    bool usePacked = b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) && dpx_tiled_stripes(b->maxM, b->R) == 1 &&
+                     numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
     if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
     if (usePacked) {
         std::vector<int32_t> idx;

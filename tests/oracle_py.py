@@ -108,21 +108,21 @@ def lsw_traceback(refs, qry, res):
     a, b, c = _tb_bufs(len(qry), len(refs))
     k = oracle().orc_lsw_traceback(refs, len(refs), qry, len(qry), _p(res.H), _p(res.dir), res.end_row, res.end_col, a, b, c)
     assert k >= 0
-    return a.value.decode("latin-1"), b.value.decode("latin-1"), c.value.decode("latin-1")
+    return a.raw[:k].decode("latin-1"), b.raw[:k].decode("latin-1"), c.raw[:k].decode("latin-1")  # sequences may hold NUL bytes
 
 
 def lnw_traceback(refs, qry, res):
     a, b, c = _tb_bufs(len(qry), len(refs))
     k = oracle().orc_lnw_traceback(refs, len(refs), qry, len(qry), _p(res.dir), a, b, c)
     assert k >= 0
-    return a.value.decode("latin-1"), b.value.decode("latin-1"), c.value.decode("latin-1")
+    return a.raw[:k].decode("latin-1"), b.raw[:k].decode("latin-1"), c.raw[:k].decode("latin-1")  # sequences may hold NUL bytes
 
 
 def anw_traceback(refs, qry, res):
     a, b, c = _tb_bufs(len(qry), len(refs))
     k = oracle().orc_anw_traceback(refs, len(refs), qry, len(qry), _p(res.dirH), _p(res.dirI), _p(res.dirD), a, b, c)
     assert k >= 0
-    return a.value.decode("latin-1"), b.value.decode("latin-1"), c.value.decode("latin-1")
+    return a.raw[:k].decode("latin-1"), b.raw[:k].decode("latin-1"), c.raw[:k].decode("latin-1")  # sequences may hold NUL bytes
 
 
 def dpx(op, a, b, c):

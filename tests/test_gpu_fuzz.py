@@ -1,0 +1,66 @@
+"""GPU parity fuzz: random shapes (incl. empty, 1-long, ragged), random byte alphabets (any byte value, matching is plain
+byte equality as in the reference), and unusual weights (zero, positive gaps, mismatch > match) -- every cell of every
+matrix, scores, start cells and traceback lines against the oracle, for all four algorithms."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+from dpx_gpu_genomics_project_amd.capi import PAIR_DTYPE
+from dpx_gpu_genomics_project_amd.synth import SynthBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def random_batch(rng, count, max_len, alphabet):
+    chunks, pairs, off = [], np.zeros(count, PAIR_DTYPE), 0
+    for p in range(count):
+        n = int(rng.integers(0, max_len + 1)) if rng.random() < 0.9 else int(rng.integers(0, 3))
+        m = int(rng.integers(0, max_len + 1)) if rng.random() < 0.9 else int(rng.integers(0, 3))
+        ref = rng.choice(alphabet, size=n).astype(np.uint8)
+        if rng.random() < 0.5 and n and m:   # related query: copy with edits
+            q = ref.copy()[: m] if m <= n else np.concatenate([ref, rng.choice(alphabet, size=m - n).astype(np.uint8)])
+            flip = rng.random(len(q)) < 0.15
+            q[flip] = rng.choice(alphabet, size=int(flip.sum()))
+            qry = q
+        else:
+            qry = rng.choice(alphabet, size=m).astype(np.uint8)
+        chunks += [ref, np.zeros(1, np.uint8), qry, np.zeros(1, np.uint8)]
+        pairs[p] = (off, n, off + n + 1, m)
+        off += n + 1 + m + 1
+    return SynthBatch(np.concatenate(chunks), pairs, max_len, max_len)
+
+
+WEIGHTS = [(3, -1, -2, -1), (1, -1, -1, -1), (2, -3, 0, -1), (0, 0, 0, 0), (5, 2, -4, -2), (1, -2, 1, -3), (7, -5, -9, 1)]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW", "BSW"])
+def test_fuzz(gpu, algo, seed):
+    rng = np.random.default_rng(1000 * seed + len(algo) + ord(algo[0]))
+    for wi, w in enumerate(WEIGHTS):
+        alphabet = [np.array([48, 49, 50, 51], np.uint8), np.arange(256, dtype=np.uint8), np.array([0, 255], np.uint8)][wi % 3]
+        sb = random_batch(rng, 24, [70, 140, 300][(wi + seed) % 3], alphabet)
+        band = int(rng.integers(1, 80))
+        code = {"LNW": gpu.ALGO_LNW, "LSW": gpu.ALGO_LSW, "ANW": gpu.ALGO_ANW, "BSW": gpu.ALGO_BSW}[algo]
+        with gpu.Batch(code, sb.sequences, sb.pairs, w[0], w[1], w[2], w[3], band=band if algo == "BSW" else 0) as b:
+            b.fill()
+            sc, er, ec = b.results()
+            for p in range(sb.num_pairs):
+                refs, qry = sb.ref(p), sb.qry(p)
+                tag = (algo, seed, w, p, len(qry), len(refs))
+                if algo == "LSW" or algo == "BSW":
+                    o = O.lsw(refs, qry, w[0], w[1], w[2], band=band if algo == "BSW" else 0)
+                    assert (sc[p], er[p], ec[p]) == (o.score, o.end_row, o.end_col), tag
+                    lines = ("", "", "") if o.score == 0 else O.lsw_traceback(refs, qry, o)
+                elif algo == "LNW":
+                    o = O.lnw(refs, qry, w[0], w[1], w[2])
+                    assert sc[p] == o.score, tag
+                    lines = O.lnw_traceback(refs, qry, o)
+                else:
+                    o = O.anw(refs, qry, *w)
+                    assert sc[p] == o.score, tag
+                    lines = O.anw_traceback(refs, qry, o)
+                    assert np.array_equal(b.matrix(p, gpu.MAT_I).astype(np.int32), o.I), tag
+                    assert np.array_equal(b.matrix(p, gpu.MAT_D).astype(np.int32), o.D), tag
+                assert np.array_equal(b.matrix(p).astype(np.int32), o.H), tag
+                assert b.traceback(p) == lines, tag
