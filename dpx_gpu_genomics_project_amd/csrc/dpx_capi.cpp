@@ -360,7 +360,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     const size_t edgeBytes = align_up((size_t)(b->maxN + 2) * 2, 16);
     const size_t nEdges = params->algo == DPX_ALGO_ANW ? 2 : 1;
     const size_t refBytes = align_up((size_t)b->maxN + 128, 16);
-    const size_t qBytes = align_up((size_t)b->maxM + 16, 16);
+    const size_t qBytes = align_up((size_t)b->maxM + 64 + 16, 16); /* banded kernel: staged query + 64 B of index slack */
     const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 16, 16); /* staged query of the rolling multi-stripe schedule */
     const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes + rollQ;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);

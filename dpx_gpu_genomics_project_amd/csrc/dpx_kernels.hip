@@ -1082,18 +1082,19 @@ struct BandState {
 /* INTERIOR: every in-band slot of this anti-diagonal lies inside the matrix, so validity is the per-lane constant
  * inBand mask (one v_and) instead of two compares against the step's slot window */
 template <int C, bool P1, bool INTERIOR>
-__device__ __forceinline__ void band_step(BandState<C> &st, const int A, const int lane, const int m, const int n, const int B,
-                                          const int match, const int mismatch, const int gap, const unsigned char *qL,
-                                          const unsigned char *rL, int *out) {
-    const int a = A + 2;
+__device__ __forceinline__ void band_step(BandState<C> &st, const int A, int &i0, int &j0, const int lane, const int m,
+                                          const int n, const int B, const int match, const int mismatch, const int gap,
+                                          const unsigned char *qL, const unsigned char *rL, int *out) {
     const int p = P1 ? 1 : 0;
-    const int i0 = (a + p - (B - 1)) >> 1; /* row of slot 0 (may be <= 0); a+p-(B-1) is even */
-    const int j0 = a - i0;                  /* column of slot 0 */
+    /* (i0, j0) = row / column of slot 0 on this anti-diagonal, kept incrementally (wave-uniform): entering a p=1 step
+     * the row advances, entering a p=0 step the column does.  i0 = (A+2 + p - (B-1)) >> 1 may be <= 0. */
+    if constexpr (P1) i0++; else j0++;
     const int smin = INTERIOR ? 0 : max(max(1 - i0, j0 - n), 0);
     const int smax = INTERIOR ? 0 : min(min(m - i0, j0 - 1), B - 1 - p);
     int up[C], left[C];
     if constexpr (P1) {
-        const int newq = qL[min(max(i0 + 64 * C - 2, 0), m - 1)];
+        /* interior: 1 <= i0 and i0 + (B-1-p) <= m, so the index stays below m + 64 (the staged query has 64 B of slack) */
+        const int newq = INTERIOR ? qL[i0 + 64 * C - 2] : qL[min(max(i0 + 64 * C - 2, 0), m - 1)];
         const int tq = wave_shl1(st.qch[0], newq);
 #pragma unroll
         for (int c = 0; c < C - 1; c++) st.qch[c] = st.qch[c + 1];
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void band_step(BandState<C> &st, const int A, const i
 #pragma unroll
         for (int c = 0; c < C; c++) { up[c] = st.prev[c]; left[c] = (c < C - 1) ? st.prev[c + 1] : nb; }
     } else {
-        const int newr = rL[min(max(j0 - 1, 0), n - 1)];
+        const int newr = INTERIOR ? rL[j0 - 1] : rL[min(max(j0 - 1, 0), n - 1)]; /* interior: 1 <= j0 <= n */
         const int tr = wave_shr1(st.rch[C - 1], newr);
 #pragma unroll
         for (int c = C - 1; c > 0; c--) st.rch[c] = st.rch[c - 1];
@@ -1182,25 +1183,30 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
     int16_t *Hp = a.mat + pr.matOff + (size_t)lane * 8u;
     const size_t cs = pr.chunkStride;
     int acc[8];
+    /* slot 0's (row, column) on the virtual anti-diagonal a = 1; band_step advances them */
+    int i0 = (1 + (B & 1) - (B - 1)) >> 1;
+    int j0 = 1 - i0;
 #define DPX_BAND_BODY(INTERIOR_)                                                                                          \
     _Pragma("unroll") for (int g = 0; g < GG; g += 2) {                                                                  \
-        band_step<C, PB, INTERIOR_>(st, A0 + g, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);          \
+        band_step<C, PB, INTERIOR_>(st, A0 + g, i0, j0, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[(g % G) * C]);  \
         if constexpr (STORE && G == 1) {                                                                                  \
-            if (A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * cs, acc);                                      \
+            if (INTERIOR_ || A0 + g < numGroups) store_tile<8>(Hp + (size_t)(A0 + g) * cs, acc);                         \
         }                                                                                                                 \
-        band_step<C, !PB, INTERIOR_>(st, A0 + g + 1, lane, m, n, B, match, mismatch, gap, qL, rL, &acc[((g + 1) % G) * C]); \
+        band_step<C, !PB, INTERIOR_>(st, A0 + g + 1, i0, j0, lane, m, n, B, match, mismatch, gap, qL, rL,                 \
+                                     &acc[((g + 1) % G) * C]);                                                            \
         if constexpr (STORE) {                                                                                            \
             if (((g + 1) % G) == G - 1) {                                                                                 \
                 const int grp = (A0 + g + 1) / G;                                                                         \
-                if (grp < numGroups) store_tile<8>(Hp + (size_t)grp * cs, acc);                                          \
+                if (INTERIOR_ || grp < numGroups) store_tile<8>(Hp + (size_t)grp * cs, acc);                             \
             }                                                                                                             \
         }                                                                                                                 \
     }
-    for (int A0 = 0; A0 < NS; A0 += GG) {
-        /* parity of step A is (A + B + 1) & 1; A0 is even, so even steps have parity PB and odd steps !PB */
-        if (interior(A0) && interior(A0 + GG - 1)) { DPX_BAND_BODY(true) }
-        else { DPX_BAND_BODY(false) }
-    }
+    /* parity of step A is (A + B + 1) & 1; A0 is even, so even steps have parity PB and odd steps !PB.
+     * Three phases: head (some slots outside the matrix), interior, tail. */
+    int A0 = 0;
+    for (; A0 < NS && !(interior(A0) && interior(A0 + GG - 1)); A0 += GG) { DPX_BAND_BODY(false) }
+    for (; A0 + GG <= NS && interior(A0 + GG - 1); A0 += GG) { DPX_BAND_BODY(true) }
+    for (; A0 < NS; A0 += GG) { DPX_BAND_BODY(false) }
 #undef DPX_BAND_BODY
     /* candidates: every slot's first maximum; rows/cols recovered from (step, slot).  Within a slot cells arrive in
      * row-major order, so the earliest step is the slot's first maximum; across slots pick max score, min row, min col */
