@@ -5,7 +5,12 @@
 // batch k (the software pipeline of V19.cu:546-579).  stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch 10000] [-device 0] [-noprint]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch 10000] [-device 0] [-noprint] [-rank r -world w]
+//
+// Multi-GPU: pairs are independent, so every GPU gets one process with its own contiguous shard of the file:
+// `-rank r -world w` aligns only pairs [ceil(N/w)*r, ceil(N/w)*(r+1)) (the same split as shard.py / bench.py) and
+// prints them with their global pair numbers; tools/run_multi_gpu.sh starts one rank per device and concatenates
+// the outputs in rank order, which is input order.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,7 +51,7 @@ int main(int argc, char *argv[]) {
         exit(EXIT_FAILURE);
     }
     const char *pairFileName = nullptr;
-    int match = 3, mismatch = -1, gapOpen = -2, gapExtend = -1, band = 128, device = 0;
+    int match = 3, mismatch = -1, gapOpen = -2, gapExtend = -1, band = 128, device = 0, rank = 0, world = 1;
     size_t batchSize = 10000; // BATCH_SIZE of the reference's final version (V19.cu:9)
     bool print = true;
     std::string algoName = "LSW";
@@ -65,9 +70,12 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-batch")) batchSize = (size_t)atoll(next("-batch"));
         else if (!strcmp(argv[i], "-device")) device = atoi(next("-device"));
         else if (!strcmp(argv[i], "-noprint")) print = false;
+        else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
+        else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
     }
     if (!pairFileName || batchSize == 0) { fprintf(stderr, "need -pairs <file>\n"); exit(EXIT_FAILURE); }
+    if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "bad -rank/-world\n"); exit(EXIT_FAILURE); }
     const int algo = algoName == "LNW" ? DPX_ALGO_LNW : algoName == "LSW" ? DPX_ALGO_LSW : algoName == "ANW" ? DPX_ALGO_ANW
                      : algoName == "BSW" ? DPX_ALGO_BSW : -1;
     if (algo < 0) { fprintf(stderr, "unknown -algo %s\n", algoName.c_str()); exit(EXIT_FAILURE); }
@@ -90,6 +98,11 @@ int main(int argc, char *argv[]) {
     char *sequences;
     inputInfo fileInfo = parseInput(pairFileName, sequenceIdxs, sequences);
     printf("Num Pairs: %zu\n\n", fileInfo.numPairs);
+    /* this rank's shard: contiguous ceil(N/world)-sized ranges */
+    const size_t perRank = (fileInfo.numPairs + (size_t)world - 1) / (size_t)world;
+    const size_t shardLo = std::min(fileInfo.numPairs, perRank * (size_t)rank);
+    const size_t shardHi = std::min(fileInfo.numPairs, shardLo + perRank);
+    if (world > 1) printf("Rank %d of %d: pairs [%zu, %zu)\n\n", rank, world, shardLo, shardHi);
 
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
@@ -99,8 +112,10 @@ int main(int argc, char *argv[]) {
 
     std::thread printer;
     BatchOut *inFlight = nullptr;
-    for (size_t first = 0; first < fileInfo.numPairs; first += batchSize) {
-        const size_t count = std::min(batchSize, fileInfo.numPairs - first);
+    size_t shardCells = 0;
+    for (size_t i = shardLo; i < shardHi; i++) shardCells += (size_t)sequenceIdxs[i].referenceSize * (size_t)sequenceIdxs[i].querySize;
+    for (size_t first = shardLo; first < shardHi; first += batchSize) {
+        const size_t count = std::min(batchSize, shardHi - first);
         uint64_t t0 = get_time();
         dpx_batch *b = nullptr;
         rc = dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, count,
@@ -154,7 +169,7 @@ int main(int argc, char *argv[]) {
     printf("Backtracking time (usec): %llu\n", (unsigned long long)backtracking_time);
     printf("Printing wait time (usec): %llu\n", (unsigned long long)printing_time);
     // GCUPS exactly as the reference computes it (V12.cu:487-491): numCells / kernel seconds / 1e9
-    printf("GCUPS: %f\n", kernel_time ? (double)fileInfo.numCells / ((double)kernel_time * 1e-6) / 1e9 : 0.0);
+    printf("GCUPS: %f\n", kernel_time ? (double)shardCells / ((double)kernel_time * 1e-6) / 1e9 : 0.0);
 
     printf("Cleaning up\n");
     cleanupParsedFile(sequenceIdxs, sequences);

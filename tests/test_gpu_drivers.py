@@ -101,3 +101,15 @@ def test_reference_testFakeDPX_passes_on_device_primitives():
         pytest.skip("oracle/_ref/testFakeDPX_dropin not built (needs /root/reference at build time)")
     out = run([exe])
     assert "PASSED ALL ASSERTIONS FOR INSTRUCTION CHECKING!!" in out
+
+
+def test_sharded_ranks_concatenate_to_the_reference_stdout():
+    """tools/run_multi_gpu.sh: 3 dpx_main ranks (all on device 0 here), each aligning its own shard of the file; the
+    concatenation of their blocks in rank order is the reference's output for the whole file."""
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    env = dict(os.environ, DPX_SHARE_GPU="1")
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_multi_gpu.sh"), "3", "-pairs", os.path.join(G, "short400.txt")] + W["ANW"] +
+                       ["-algo", "ANW", "-batch", "70"], capture_output=True, text=True, encoding="latin-1", env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == golden("ANW")
+    assert "[rank 2] Rank 2 of 3: pairs [268, 400)" in r.stderr
