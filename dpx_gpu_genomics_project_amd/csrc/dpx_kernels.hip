@@ -101,6 +101,15 @@ struct LinState {
     int dtop;         /* H[row0][j-1]: diagonal of the lane's top row */
 };
 
+/* Single-stripe pairs shorter than 64*R rows leave the upper lanes without rows; those lanes need not store.  Returns
+ * the number of lanes that do: the row-owning lanes rounded up to whole 64-byte sectors of the store. */
+template <int R>
+__device__ __forceinline__ int store_lanes(const int m) {
+    constexpr int perSector = 64 / (2 * (R < 8 ? R : 8)); /* lanes per 64-byte sector: 16 / 8 / 4 for R = 2 / 4 / >= 8 */
+    const int owning = (m + R - 1) / R;
+    return min(64, (owning + perSector - 1) / perSector * perSector);
+}
+
 /* the R chained cells of one lane for one column (shared by the striped and the rolling schedule) */
 template <int R, bool LOCAL, bool KEYS>
 __device__ __forceinline__ void lin_cells(LinState<R, LOCAL> &st, const int upin, const int rc, const int j, const int match,
@@ -237,7 +246,7 @@ template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
                                          const bool laneHasRows, const int match, const int mismatch, const int gap,
                                          const int e0, const int rc, int16_t *edge, const bool writeEdge,
-                                         int16_t *tileDst) {
+                                         int16_t *tileDst, const int storeLanes) {
     const int j = t - lane + 1;
     /* cross-lane traffic happens with all lanes enabled: a finished lane must still feed its neighbour */
     const int upin = wave_shr1(st.Hl[R - 1], e0);
@@ -258,7 +267,9 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
      * its whole 64*R*2-byte chunk.  Partial chunks (masked stores) measured ~2.5x the cost of full ones -- a chunk
      * with a partly written 64-B sector becomes a read-modify-write at the HBM.  The extra bytes land in the skew
      * padding of the pair's block, which nothing ever reads. */
-    if constexpr (STORE && (!MASKED || WHOLE) && !(MASKED && DPX_EXP_NORAMPSTORE)) store_words<R>(tileDst, w);
+    if constexpr (STORE && (!MASKED || WHOLE) && !(MASKED && DPX_EXP_NORAMPSTORE)) {
+        if (lane < storeLanes) store_words<R>(tileDst, w); /* storeLanes == 64 unless the pair is shorter than the stripe */
+    }
 }
 
 template <int R, bool LOCAL, bool STORE>
@@ -401,9 +412,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 rcN = rp[t + 1];                                                                                      \
                 e0N = edge[min(t + 2, n + 1)];                                                                        \
                 lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
-                                                           hasNext, tile + (size_t)t * cs);                          \
+                                                           hasNext, tile + (size_t)t * cs, storeLanes);              \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
+            const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
             if (S == 1) { /* the ramp chunks belong to this stripe alone: store them whole */
                 if (fast) {
                     int t = 0;
@@ -672,7 +684,8 @@ __device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, cons
 template <int R, bool LOCAL, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                         const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP, const uint32_t e0,
-                                        const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB) {
+                                        const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB,
+                                        const int storeLanes) {
     const int j = t - lane + 1;
     const uint32_t upin = (uint32_t)wave_shr1((int)st.Hl[R - 1], (int)e0);
     bool active = true;
@@ -707,7 +720,9 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
         if (writeEdge && lane == 63) edge[j] = st.Hl[R - 1];
         if constexpr (MASKED && !WHOLE) store_tile_pk<R>(tileA, tileB, st.Hl);
     }
-    if constexpr (!MASKED || WHOLE) store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks (see lin_step) */
+    if constexpr (!MASKED || WHOLE) {
+        if (lane < storeLanes) store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks (see lin_step) */
+    }
 }
 
 template <int R, bool LOCAL>
@@ -771,9 +786,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
             e0N = edge[min(t + 2, n + 1)];                                                                            \
             const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u); /* {A char, B char} -> 16-bit lanes */  \
             pk_step<R, LOCAL, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext, \
-                                       tileA + (size_t)t * csA, tileB + (size_t)t * csB);                            \
+                                       tileA + (size_t)t * csA, tileB + (size_t)t * csB, storeLanes);                \
         }
         const bool fast = (base + 64 * R <= m) && (n >= 64);
+        const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
         if (S == 1) {
             if (fast) {
                 int t = 0;
@@ -866,7 +882,7 @@ template <int R, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                          const int match, const int mismatch, const int oe, const int e, const int e0H,
                                          const int e0D, const int rc, int16_t *edgeH, int16_t *edgeD,
-                                         const bool writeEdge, int16_t *tileDst) {
+                                         const bool writeEdge, int16_t *tileDst, const int storeLanes) {
     const int j = t - lane + 1;
     const int upH = wave_shr1(st.Hl[R - 1], e0H);
     const int upD = wave_shr1(st.Dl[R - 1], e0D);
@@ -885,9 +901,11 @@ __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int
         }
     }
     if constexpr (STORE && (!MASKED || WHOLE)) { /* whole chunks, also on the skew ramps (see lin_step) */
-        store_tile<R>(tileDst, st.Hl);
-        store_tile<R>(tileDst + 64 * R, st.Il);
-        store_tile<R>(tileDst + 128 * R, st.Dl);
+        if (lane < storeLanes) {
+            store_tile<R>(tileDst, st.Hl);
+            store_tile<R>(tileDst + 64 * R, st.Il);
+            store_tile<R>(tileDst + 128 * R, st.Dl);
+        }
     }
 }
 
@@ -1024,9 +1042,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
                 eHN = edgeH[min(t + 2, n + 1)];                                                                           \
                 eDN = k == 0 ? DPX_NEG : (int)edgeD[min(t + 2, n + 1)];                                                   \
                 aff_step<R, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, oe, e, eH, eD, rc, edgeH, edgeD, \
-                                            hasNext, tile + (size_t)t * cs);                                              \
+                                            hasNext, tile + (size_t)t * cs, storeLanes);                                  \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
+            const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
             if (S == 1) {
                 if (fast) {
                     int t = 0;
