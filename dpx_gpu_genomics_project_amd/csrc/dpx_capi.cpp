@@ -106,7 +106,45 @@ void pool_release(void *ptr, size_t bytes) {
     if (evict) (void)hipFree(evict);
 }
 
+/* the same parking trick for the traceback line buffers (device + pinned host mirror): pinning ~70 MB costs ~10 ms */
+struct SlotCache {
+    std::mutex mu;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+SlotCache g_tbDev, g_tbHost;
+
+void *slot_take(SlotCache &c, size_t bytes, size_t *actual) {
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.ptr && c.bytes >= bytes && c.bytes <= 2 * bytes + (1u << 20)) {
+        void *p = c.ptr;
+        *actual = c.bytes;
+        c.ptr = nullptr;
+        c.bytes = 0;
+        return p;
+    }
+    return nullptr;
+}
+
+/* returns the buffer that must be freed by the caller (the evicted one, or `ptr` itself when it is not worth parking) */
+void *slot_park(SlotCache &c, void *ptr, size_t bytes) {
+    if (!ptr) return nullptr;
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (bytes < (1u << 20)) return ptr;
+    void *evict = c.ptr;
+    c.ptr = ptr;
+    c.bytes = bytes;
+    return evict;
+}
+
 void pool_trim() {
+    {
+        void *d = nullptr, *h = nullptr;
+        { std::lock_guard<std::mutex> lk(g_tbDev.mu); d = g_tbDev.ptr; g_tbDev.ptr = nullptr; g_tbDev.bytes = 0; }
+        { std::lock_guard<std::mutex> lk(g_tbHost.mu); h = g_tbHost.ptr; g_tbHost.ptr = nullptr; g_tbHost.bytes = 0; }
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+    }
     void *stale = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -153,7 +191,9 @@ struct dpx_batch {
     char *dTb = nullptr;
     int32_t *dTbLen = nullptr;
     std::vector<uint64_t> tbOff;
-    std::vector<char> hTb;
+    char *hTb = nullptr;   /* pinned host mirror of the line buffers (pageable D2H of ~70 MB costs 3-4x more) */
+    size_t hTbBytes = 0;   /* bytes of line data */
+    size_t dTbCap = 0, hTbCap = 0; /* capacities of the (possibly recycled) buffers */
     std::vector<int32_t> hTbLen;
     bool tbValid = false;
 };
@@ -266,8 +306,9 @@ int dpx_batch_destroy(dpx_batch *b) {
     (void)hipFree(b->dEndRow);
     (void)hipFree(b->dEndCol);
     (void)hipFree(b->dTbOff);
-    (void)hipFree(b->dTb);
+    if (void *ev = slot_park(g_tbDev, b->dTb, b->dTbCap)) (void)hipFree(ev);
     (void)hipFree(b->dTbLen);
+    if (void *ev = slot_park(g_tbHost, b->hTb, b->hTbCap)) (void)hipHostFree(ev);
     delete b;
     return DPX_OK;
 }
@@ -678,17 +719,21 @@ static int run_traceback(dpx_batch *b) {
         for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)(b->pairs[i].m + b->pairs[i].n + 1); }
         b->tbOff[np] = off;
         HIP_TRY(hipMalloc((void **)&b->dTbOff, (np + 1) * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void **)&b->dTb, std::max<uint64_t>(off, 16)));
+        const size_t need = (size_t)std::max<uint64_t>(off, 16);
+        if (void *rec = slot_take(g_tbDev, need, &b->dTbCap)) b->dTb = (char *)rec;
+        else { HIP_TRY(hipMalloc((void **)&b->dTb, need)); b->dTbCap = need; }
         HIP_TRY(hipMalloc((void **)&b->dTbLen, std::max<size_t>(np, 1) * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        b->hTb.resize(off);
+        b->hTbBytes = off;
+        if (void *rec = slot_take(g_tbHost, need, &b->hTbCap)) b->hTb = (char *)rec;
+        else { HIP_TRY(hipHostMalloc((void **)&b->hTb, need, hipHostMallocDefault)); b->hTbCap = need; }
         b->hTbLen.resize(np);
     }
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(dpx_launch_traceback(b->args, (int)b->numPairs, b->kernelAlgo, b->R, b->planes, b->dTbOff, b->dTb, b->dTbLen, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (np) {
-        HIP_TRY(hipMemcpy(b->hTb.data(), b->dTb, b->hTb.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b->hTb, b->dTb, b->hTbBytes, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(b->hTbLen.data(), b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
     b->tbValid = true;
@@ -705,7 +750,7 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
     if (rc != DPX_OK) return rc;
     const int cap = b->pairs[pair].m + b->pairs[pair].n + 1;
     const int k = b->hTbLen[pair];
-    const char *base = b->hTb.data() + b->tbOff[pair];
+    const char *base = b->hTb + b->tbOff[pair];
     char *dst[3] = {refLine, relLine, qryLine};
     for (int l = 0; l < 3; l++)
         if (dst[l]) { memcpy(dst[l], base + (size_t)l * cap + (cap - k), (size_t)k); dst[l][k] = 0; }

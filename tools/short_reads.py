@@ -15,7 +15,9 @@ for algo in (dpx.ALGO_LNW, dpx.ALGO_LSW, dpx.ALGO_ANW):
         us = min(b.fill_timed(3) for _ in range(3))
         extra = ""
         if not flags:
-            t = time.time(); b.traceback(0); extra = f"  traceback(all pairs)+D2H {1e3*(time.time()-t):.1f} ms"
+            t = time.time(); b.traceback(0); t1 = time.time() - t
+            b.fill(); b.sync(); t = time.time(); b.traceback(0); t2 = time.time() - t
+            extra = f"  traceback(all pairs)+D2H first {1e3*t1:.1f} ms, again {1e3*t2:.1f} ms"
         info = b.info()
         print(f"{dpx.ALGO_NAMES[algo]} flags={flags}: {us/1e3:.3f} ms  {sb.cells/us/1e3:.1f} GCUPS  alg {info['algorithmic_bytes']/us/1e3:.0f} GB/s  mat {info['matrix_bytes']/1e9:.2f} GB{extra}", flush=True)
         b.close()
