@@ -183,6 +183,9 @@ struct dpx_batch {
     bool streamed = false; /* uniform batch on the stream schedule (k_linear_stream) */
     size_t streamLds = 0;
     bool packed = false;
+    bool quad = false;     /* short queries: four pairs per wave (k_linear_quad); slots in dCouples: first the pairs of
+                              <= 128 rows (8 rows per lane, pkArgs), then those of <= 256 (16 rows per lane, q16Args) */
+    dpx_fill_args q16Args{};
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
     size_t pkLdsBytes = 0;
@@ -380,7 +383,8 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         dpx_pair_dev &pd = b->pairs[i];
         pd.matOff = 0;
         pd.chunkStride = 0;
-        pd.pad_ = 0;
+        pd.lanes = 64;
+        pd.rows = 0;
         b->algBytes += (uint64_t)pd.m + (uint64_t)pd.n + 16u + 12u;
         if (b->store) {
             if (banded) { /* 2 B per in-band cell */
@@ -426,12 +430,40 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
     /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
     std::vector<int32_t> singles, couples;
+    size_t numQuad8 = 0;
     /* "+Opt" packed path (two equal-shaped pairs per wave on the v_pk_*_i16 pipe).  The fill is bound by store
      * instructions per CU-cycle, so halving the VALU work buys no cycles -- it buys clock: the chip holds ~2.3 GHz
      * instead of ~2.1 GHz under the lighter instruction stream (profiles/README.md), 4-7 % wall time.  Used when every
      * query fits one stripe (the packed kernel has no rolling schedule); DPX_PACKED=0/1 overrides. */
-    bool usePacked = b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) && dpx_tiled_stripes(b->maxM, b->R) == 1 &&
+    /* Quad path (short reads, the reference's own dataset shape): queries of <= 256 rows in a batch large enough to fill
+     * the chip with a quarter of the waves run four pairs per wave, one per 16-lane DPP row; DPX_QUAD=0/1 overrides. */
+    const bool linearAlgo = kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW;
+    const bool quadAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
+    bool useQuad = quadAlgo && b->maxM <= 256 && b->maxM > 0 && numPairs >= 8192;
+    if (const char *env = getenv("DPX_QUAD")) useQuad = atoi(env) != 0 && quadAlgo && b->maxM <= 256 && b->maxM > 0;
+    if (useQuad) {
+        b->R = 8; /* empty pairs, if any, run on the one-pair-per-wave kernel at this tile height (they have no cells) */
+        for (size_t i = 0; i < numPairs; i++) {
+            dpx_pair_dev &pd = b->pairs[i];
+            if (pd.m > 0 && pd.n > 0) { couples.push_back((int32_t)i); pd.lanes = 16; pd.rows = pd.m <= 128 ? 8 : 16; }
+            else singles.push_back((int32_t)i);
+        }
+        /* 8-row pairs first, then 16-row pairs; inside a class the four pairs of a wave run max(n)+15 steps, so
+         * neighbours of similar reference length, longest first */
+        std::stable_sort(couples.begin(), couples.end(), [&](int32_t x, int32_t y) {
+            const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
+            if (X.rows != Y.rows) return X.rows < Y.rows;
+            if (X.n != Y.n) return X.n > Y.n;
+            return X.m > Y.m;
+        });
+        for (int32_t c : couples) numQuad8 += b->pairs[c].rows == 8;
+        b->quad = !couples.empty();
+        if (!b->quad) { b->R = R; singles.clear(); }
+    }
+    bool usePacked = !b->quad && b->store && linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1 &&
                      numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
+    if (b->quad) usePacked = false;
+    else
     if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
     if (usePacked) {
         std::vector<int32_t> idx;
@@ -460,7 +492,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         }
         b->packed = !couples.empty();
     }
-    if (b->packed) {
+    if (b->packed || b->quad) {
         CREATE_TRY(hipMalloc((void **)&b->dCouples, couples.size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     } else if (ragged) {
@@ -474,13 +506,13 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         CREATE_TRY(hipMalloc((void **)&b->dOrder, singles.size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    const size_t numSingles = b->packed ? singles.size() : numPairs;
+    const size_t numSingles = (b->packed || b->quad) ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
     /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
     int numStreams = 0;
     {
-        bool want = b->store && !b->packed && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
+        bool want = b->store && !b->packed && !b->quad && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
                     b->pairs[0].m > 0 && b->pairs[0].n >= 128;
         /* opt-in: bit-exact and 3 % fewer bytes written, but not faster than one launch-scheduled wave per pair -- the
          * fill is bound by store instructions per CU-cycle either way (profiles/README.md) */
@@ -512,10 +544,11 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 4096) group = v; }
         const uint32_t chunkElems = banded ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
         auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
+            if (pd.lanes == 16) return dpx_quad_chunks(pd.m, pd.n);
             return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
         };
         uint64_t off = 0;
-        auto place = [&](const std::vector<int32_t> &slots, size_t slotsPerGroup) { /* slots in launch order */
+        auto place = [&](const std::vector<int32_t> &slots, size_t slotsPerGroup, uint32_t chunkElems) { /* slots in launch order */
             for (size_t s0 = 0; s0 < slots.size(); s0 += slotsPerGroup) {
                 const size_t cnt = std::min(slotsPerGroup, slots.size() - s0);
                 uint64_t maxChunks = 0;
@@ -546,14 +579,18 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
                 }
                 off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
             }
-        } else if (b->packed) place(couples, (size_t)group * 2); /* one wave = two adjacent slots */
+        } else if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave = two adjacent slots */
+        else if (b->quad) { /* one wave = four adjacent slots */
+            place(std::vector<int32_t>(couples.begin(), couples.begin() + numQuad8), (size_t)group * 4, 16u * 8u * (uint32_t)b->planes);
+            place(std::vector<int32_t>(couples.begin() + numQuad8, couples.end()), (size_t)group * 4, 16u * 16u * (uint32_t)b->planes);
+        }
         if (b->streamed) {
-        } else if (b->packed || !singles.empty()) {
-            place(singles, (size_t)group);
+        } else if (b->packed || b->quad || !singles.empty()) {
+            place(singles, (size_t)group, chunkElems);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
             std::iota(ident.begin(), ident.end(), 0);
-            place(ident, (size_t)group);
+            place(ident, (size_t)group, chunkElems);
         }
         b->matElems = off;
     }
@@ -603,6 +640,22 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
+    if (b->quad) { /* per wave: four staged references [16 + n + 32] */
+        dpx_fill_args &k = b->pkArgs;
+        k = a;
+        k.order = b->dCouples;
+        k.numPairs = (int32_t)numQuad8;
+        const size_t refStride = align_up((size_t)b->maxN + 48, 16);
+        k.ldsBufStride = (uint32_t)refStride;
+        k.ldsPerWave = (uint32_t)(4 * refStride);
+        b->pkLdsBytes = 4 * refStride * (DPX_FILL_THREADS / 64);
+        if (b->store && b->pkLdsBytes < 36u * 1024u) b->pkLdsBytes = 36u * 1024u; /* store-bound: 4 workgroups per CU (see above) */
+        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
+        if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+        b->q16Args = k;
+        b->q16Args.order = b->dCouples + numQuad8;
+        b->q16Args.numPairs = (int32_t)(couples.size() - numQuad8);
+    }
     *out = b;
     return DPX_OK;
 }
@@ -612,6 +665,12 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     if (b->packed) {
         hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
         if (e != hipSuccess) return e;
+    }
+    if (b->quad) {
+        hipError_t e = dpx_launch_fill_quad(b->pkArgs, b->kernelAlgo, 8, b->store, b->pkLdsBytes, s);
+        if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->pkLdsBytes, s);
+        if (e != hipSuccess) return e;
+        if (b->args.numPairs == 0) return hipSuccess; /* no empty pairs left for the one-pair-per-wave kernel */
     }
     if (b->streamed) return dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
     hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);

@@ -40,6 +40,7 @@ typedef struct dpx_fill_args {
 } dpx_fill_args;
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
+hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_sw_locate(const dpx_fill_args &a, int R, hipStream_t stream);

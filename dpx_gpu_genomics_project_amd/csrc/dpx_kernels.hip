@@ -102,12 +102,14 @@ struct LinState {
 };
 
 /* Single-stripe pairs shorter than 64*R rows leave the upper lanes without rows; those lanes need not store.  Returns
- * the number of lanes that do: the row-owning lanes rounded up to whole 64-byte sectors of the store. */
+ * the number of lanes that do: the row-owning lanes rounded up to whole 128-byte lines of the store (a line written
+ * in part costs a read-modify-write at the memory side: rounding to 64-byte sectors measured 25 % slower on the
+ * short-read batch, profiles/README.md). */
 template <int R>
 __device__ __forceinline__ int store_lanes(const int m) {
-    constexpr int perSector = 64 / (2 * (R < 8 ? R : 8)); /* lanes per 64-byte sector: 16 / 8 / 4 for R = 2 / 4 / >= 8 */
+    constexpr int perLine = 128 / (2 * (R < 8 ? R : 8)); /* lanes per 128-byte line: 32 / 16 / 8 for R = 2 / 4 / >= 8 */
     const int owning = (m + R - 1) / R;
-    return min(64, (owning + perSector - 1) / perSector * perSector);
+    return min(64, (owning + perLine - 1) / perLine * perLine);
 }
 
 /* the R chained cells of one lane for one column (shared by the striped and the rolling schedule) */
@@ -461,6 +463,106 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             a.score[p] = v;
             a.endRow[p] = m;
             a.endCol[p] = n;
+        }
+    }
+}
+
+/* =====================================================================================================
+ * Quad kernel for short queries (the reference's own dataset shape: reads of 80-150 bases, cuda/LNW V12 on
+ * bsw/small): FOUR pairs per wave, one per 16-lane DPP row.  Lane l of a row owns rows [l*R, l*R+R) of its pair (16*R
+ * rows: 128 at R = 8, 256 at R = 16), `up` moves with `v_mov_b32_dpp row_shr:1` (lanes 0/16/32/48 have no source and
+ * keep the row-0 border), so the skew ramp is 15 steps instead of 63 and a 100-row query keeps 13 of 16 lanes busy
+ * instead of 13 (or 25) of 64.  The four pairs may differ in shape: n, m, pointers are per-lane values, the wave runs
+ * max(n)+15 steps and every row masks itself.  Each row stores its own 16*R*2-byte chunk per step; the host places
+ * the four pairs of a wave next to each other so the wave's store covers one contiguous 4-chunk block.
+ * ===================================================================================================== */
+__device__ __forceinline__ int row_shr1(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x111, 0xf, 0xf, false); }
+
+template <int R, bool LOCAL, bool STORE>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    if (4 * w >= a.numPairs) return; /* wave-uniform */
+    const int q = lane >> 4, l = lane & 15;
+    const int slot = 4 * w + q;
+    const bool has = slot < a.numPairs;
+    const int p = has ? (a.order ? a.order[slot] : slot) : 0;
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = has ? pr.n : 0, m = has ? pr.m : 0; /* per DPP row */
+    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+
+    unsigned char *refl = smem + (size_t)wv * a.ldsPerWave + (size_t)q * a.ldsBufStride; /* this row's reference: [16 + (j-1)] */
+    for (int x = l; x < n; x += 16) refl[16 + x] = ref[x];
+
+    const int row0 = l * R;
+    const int nrows = min(max(m - row0, 0), R);
+    LinState<R, LOCAL> st;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+        st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+        st.key[r] = 0u;
+    }
+    st.dtop = LOCAL ? 0 : row0 * gap;
+
+    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
+                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+    const int storeLanes = min(16, ((m + R - 1) / R + 7) & ~7); /* whole 128-byte lines (8 lanes x 16 B), see store_lanes */
+    int16_t *tile = a.mat + pr.matOff + (size_t)l * (R < 8 ? R : 8);
+    const size_t cs = pr.chunkStride;
+    const unsigned char *rp = refl + 16 - l; /* rp[t] = reference character of column j = t - l + 1 */
+    int rcN = rp[0];
+    const int steps = nmax + 15;
+    for (int t = 0; t < steps; t++) {
+        const int j = t - l + 1;
+        const int rc = rcN;
+        rcN = rp[t + 1];
+        const int upin = row_shr1(st.Hl[R - 1], LOCAL ? 0 : (t + 1) * gap); /* lanes 0/16/32/48: row-0 border of column t+1 */
+        if (has && nrows > 0 && j >= 1 && j <= n) lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
+        if constexpr (STORE) {
+            if (has && t < n + 15 && l < storeLanes) { /* whole chunks of this row's pair while it is running */
+                uint32_t wd[(R + 1) / 2];
+                lin_pack<R, LOCAL, false>(st, wd);
+                int16_t *dst = tile + (size_t)t * cs;
+                if constexpr (R <= 4) {
+                    store_words<R>(dst, wd);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < R / 8; h++) {
+                        u32x4 v = {wd[4 * h + 0], wd[4 * h + 1], wd[4 * h + 2], wd[4 * h + 3]};
+                        stream_store(reinterpret_cast<u32x4 *>(dst + h * 128), v); /* sub-tile h: [16 lanes][8] */
+                    }
+                }
+            }
+        }
+    }
+    if (!has) return;
+    if constexpr (LOCAL) {
+        int bestv = 0, bestrow = 0, bestcol = 0;
+        lin_fold_keys<R, LOCAL, true>(st, row0, nrows, bestv, bestrow, bestcol);
+        const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
+        unsigned long long top = mine;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { /* xor offsets < 16 stay inside the 16-lane row */
+            const unsigned long long o = __shfl_xor(top, off, 64);
+            top = o > top ? o : top;
+        }
+        if ((int)(top >> 32) == 0) {
+            if (l == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
+        } else if (mine == top) {
+            a.score[p] = bestv; a.endRow[p] = bestrow; a.endCol[p] = bestcol;
+        }
+    } else {
+        const int lm = (m - 1) / R, rm = (m - 1) % R; /* owner of row m: its registers hold column n after its last step */
+        if (l == lm) {
+            int v = st.Hl[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+            a.score[p] = v; a.endRow[p] = m; a.endCol[p] = n;
         }
     }
 }
@@ -1078,6 +1180,87 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
     }
 }
 
+/* Affine quad kernel: the Gotoh recurrence of k_affine_fill on the four-pairs-per-wave schedule of k_linear_quad
+ * (16 lanes per pair, `up` of H and D through row_shr:1, three planes [H][I][D] of [16 lanes][8] sub-tiles per step). */
+template <int R, bool STORE>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    if (4 * w >= a.numPairs) return; /* wave-uniform */
+    const int q = lane >> 4, l = lane & 15;
+    const int slot = 4 * w + q;
+    const bool has = slot < a.numPairs;
+    const int p = has ? (a.order ? a.order[slot] : slot) : 0;
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = has ? pr.n : 0, m = has ? pr.m : 0;
+    const int match = a.match, mismatch = a.mismatch;
+    const int o = a.gapOpen, e = a.gapExtend, oe = o + e;
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+
+    unsigned char *refl = smem + (size_t)wv * a.ldsPerWave + (size_t)q * a.ldsBufStride;
+    for (int x = l; x < n; x += 16) refl[16 + x] = ref[x];
+
+    const int row0 = l * R;
+    const int nrows = min(max(m - row0, 0), R);
+    AffState<R> st;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
+        st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (AffineNeedlemanWunsch.cpp:43-46) */
+        st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
+        st.Dl[r] = DPX_NEG;
+    }
+    st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
+
+    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
+                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+    const int storeLanes = min(16, ((m + R - 1) / R + 7) & ~7); /* whole 128-byte lines (8 lanes x 16 B), see store_lanes */
+    int16_t *tile = a.mat + pr.matOff + (size_t)l * 8;
+    const size_t cs = pr.chunkStride;
+    const unsigned char *rp = refl + 16 - l;
+    int rcN = rp[0];
+    const int steps = nmax + 15;
+    for (int t = 0; t < steps; t++) {
+        const int j = t - l + 1;
+        const int rc = rcN;
+        rcN = rp[t + 1];
+        const int upH = row_shr1(st.Hl[R - 1], o + (t + 1) * e); /* row-0 border H[0][j] = o + j*e (:50-53) */
+        const int upD = row_shr1(st.Dl[R - 1], DPX_NEG);         /* virtual D[0][j] */
+        if (has && nrows > 0 && j >= 1 && j <= n) aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
+        if constexpr (STORE) {
+            if (has && t < n + 15 && l < storeLanes) {
+                int16_t *dst = tile + (size_t)t * cs;
+#pragma unroll
+                for (int h = 0; h < R / 8; h++) {
+                    u32x4 vh = {pack_lo16(st.Hl[8 * h + 0], st.Hl[8 * h + 1]), pack_lo16(st.Hl[8 * h + 2], st.Hl[8 * h + 3]),
+                                pack_lo16(st.Hl[8 * h + 4], st.Hl[8 * h + 5]), pack_lo16(st.Hl[8 * h + 6], st.Hl[8 * h + 7])};
+                    u32x4 vi = {pack_lo16(st.Il[8 * h + 0], st.Il[8 * h + 1]), pack_lo16(st.Il[8 * h + 2], st.Il[8 * h + 3]),
+                                pack_lo16(st.Il[8 * h + 4], st.Il[8 * h + 5]), pack_lo16(st.Il[8 * h + 6], st.Il[8 * h + 7])};
+                    u32x4 vd = {pack_lo16(st.Dl[8 * h + 0], st.Dl[8 * h + 1]), pack_lo16(st.Dl[8 * h + 2], st.Dl[8 * h + 3]),
+                                pack_lo16(st.Dl[8 * h + 4], st.Dl[8 * h + 5]), pack_lo16(st.Dl[8 * h + 6], st.Dl[8 * h + 7])};
+                    constexpr int Q = R / 8;
+                    stream_store(reinterpret_cast<u32x4 *>(dst + (0 * Q + h) * 128), vh);
+                    stream_store(reinterpret_cast<u32x4 *>(dst + (1 * Q + h) * 128), vi);
+                    stream_store(reinterpret_cast<u32x4 *>(dst + (2 * Q + h) * 128), vd);
+                }
+            }
+        }
+    }
+    if (!has) return;
+    const int lm = (m - 1) / R, rm = (m - 1) % R;
+    if (l == lm) {
+        int v = st.Hl[0];
+#pragma unroll
+        for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+        a.score[p] = v; /* scoringMemo[m][n] (:365) */
+        a.endRow[p] = m;
+        a.endCol[p] = n;
+    }
+}
+
 /* =====================================================================================================
  * Banded Smith-Waterman (python/LinearBandedSmithWaterman.py:62-104): the LSW recurrence restricted to
  * |i-j| <= B-1; every cell outside the band (and the borders) reads as 0.
@@ -1260,6 +1443,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
 __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, int R, int planes, int plane, int gapOpen,
                                 int gapExtend, int band, int16_t *out) {
     const int n = pr.n, m = pr.m;
+    if (pr.rows) R = pr.rows;
     const size_t total = (size_t)(m + 1) * (size_t)(n + 1);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(idx / (size_t)(n + 1));
@@ -1275,7 +1459,7 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
             const int dlt = i - j;
             v = (dlt <= band - 1 && -dlt <= band - 1) ? mat[pr.matOff + dpx_band_index(i, j, band, pr.chunkStride)] : 0;
         } else {
-            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, plane, pr.chunkStride)];
+            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, plane, pr.chunkStride, pr.lanes)];
         }
         out[idx] = (int16_t)v;
     }
@@ -1294,7 +1478,7 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
 struct TbView {
     const int16_t *mat;
     uint64_t off;
-    uint32_t cs;
+    uint32_t cs, lanes;
     int n, m, R, planes, algo, band, gapOpen, gapExtend;
     __device__ __forceinline__ int get(int i, int j, int plane) const {
         if (i == 0 || j == 0) { /* closed-form borders, as in k_export_matrix */
@@ -1309,7 +1493,7 @@ struct TbView {
             if (dlt > band - 1 || -dlt > band - 1) return 0;
             return mat[off + dpx_band_index(i, j, band, cs)];
         }
-        return mat[off + dpx_tiled_index(i, j, n, R, plane, cs)];
+        return mat[off + dpx_tiled_index(i, j, n, R, plane, cs, lanes)];
     }
 };
 
@@ -1325,7 +1509,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
     char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
     int pos = cap; /* lines grow from the back */
     const int match = a.match, mismatch = a.mismatch;
-    TbView v{a.mat, pr.matOff, pr.chunkStride, n, m, R, planes, algo, a.band, a.gapOpen, a.gapExtend};
+    TbView v{a.mat, pr.matOff, pr.chunkStride, pr.lanes, n, m, pr.rows ? (int)pr.rows : R, planes, algo, a.band, a.gapOpen, a.gapExtend};
 #define EMIT(rc_, xc_, qc_) { --pos; lr[pos] = (char)(rc_); lx[pos] = (char)(xc_); lq[pos] = (char)(qc_); }
     int i = endRow[p], j = endCol[p];
     if (algo == DPX_K_LSW || algo == DPX_K_BSW) {
@@ -1509,6 +1693,33 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
         }
     }
     return hipErrorInvalidValue;
+}
+
+/* quad kernel (short queries): a.order = pair slots, 4 per wave; a.numPairs = number of slots */
+hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    const int pairsPerBlock = 4 * (DPX_FILL_THREADS / 64);
+    dim3 grid((unsigned)((a.numPairs + pairsPerBlock - 1) / pairsPerBlock));
+    if (algo == DPX_K_ANW) {
+        if (R == 8) return store ? launch_fill_kernel(k_affine_quad<8, true>, a, grid, ldsBytes, stream)
+                                 : launch_fill_kernel(k_affine_quad<8, false>, a, grid, ldsBytes, stream);
+        if (R == 16) return store ? launch_fill_kernel(k_affine_quad<16, true>, a, grid, ldsBytes, stream)
+                                  : launch_fill_kernel(k_affine_quad<16, false>, a, grid, ldsBytes, stream);
+        return hipErrorInvalidValue;
+    }
+    const bool local = algo == DPX_K_LSW;
+#define DPX_QUAD_CASE(R_)                                                                                          \
+    case R_:                                                                                                      \
+        if (local) return store ? launch_fill_kernel(k_linear_quad<R_, true, true>, a, grid, ldsBytes, stream)    \
+                                : launch_fill_kernel(k_linear_quad<R_, true, false>, a, grid, ldsBytes, stream);  \
+        return store ? launch_fill_kernel(k_linear_quad<R_, false, true>, a, grid, ldsBytes, stream)              \
+                     : launch_fill_kernel(k_linear_quad<R_, false, false>, a, grid, ldsBytes, stream);
+    switch (R) {
+        DPX_QUAD_CASE(8)
+        DPX_QUAD_CASE(16)
+    default: return hipErrorInvalidValue;
+    }
+#undef DPX_QUAD_CASE
 }
 
 /* stream schedule (uniform batches): a.numStreams persistent waves, each fills its pairs back to back */

@@ -47,7 +47,8 @@ typedef struct dpx_pair_dev {
     int32_t qryIdx, m;  /* query offset / length      (rows)    */
     uint64_t matOff;    /* first int16 element of this pair's chunk 0 */
     uint32_t chunkStride; /* int16 elements between consecutive chunks (steps) of this pair */
-    uint32_t pad_;
+    uint16_t lanes;       /* lanes that own this pair's rows: 64 (one wave per pair) or 16 (quad kernel: 4 pairs per wave) */
+    uint16_t rows;        /* rows per lane of the kernel that fills this pair (quad batches mix 8 and 16); 0 = the batch's */
 } dpx_pair_dev;
 
 /* number of stripes / elements of one pair's block */
@@ -64,8 +65,19 @@ DPX_HD uint32_t dpx_tile_off(int R, int plane, int l, int r) {
     const int Rq = R < 8 ? R : 8, Q = R / Rq;
     return (uint32_t)(((plane * Q + r / Rq) * 64 + l) * Rq + r % Rq);
 }
+/* Quad layout (short queries, 4 pairs per wave): a pair's rows belong to 16 lanes, l = (i-1)/R, single stripe of 16*R
+ * rows, chunk T = (j-1) + l holds [plane][sub-tile][16 lanes][<=8 rows]; n + 15 chunks per pair. */
+DPX_HD uint64_t dpx_quad_chunks(int m, int n) { return (m <= 0 || n <= 0) ? 0 : (uint64_t)n + 15u; }
+DPX_HD uint32_t dpx_quad_tile_off(int R, int plane, int l, int r) {
+    const int Rq = R < 8 ? R : 8, Q = R / Rq;
+    return (uint32_t)(((plane * Q + r / Rq) * 16 + l) * Rq + r % Rq);
+}
 /* offset of cell (i, j) of `plane` relative to the pair's matOff */
-DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride) {
+DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride, uint32_t lanes = 64) {
+    if (lanes == 16) {
+        const int l = (i - 1) / R, r = (i - 1) % R;
+        return (uint64_t)((j - 1) + l) * (uint64_t)chunkStride + (uint64_t)dpx_quad_tile_off(R, plane, l, r);
+    }
     int i0 = i - 1;
     int k = i0 / (64 * R);
     int l = (i0 % (64 * R)) / R;
