@@ -422,6 +422,18 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     } while (0)
 
     CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    /* only the bytes this batch's pairs touch go to the device (a driver that cuts one big file into batches hands the
+     * whole file to every dpx_batch_create): upload [seqLo, seqHi) and rebase the device-side indices */
+    size_t seqLo = numBytes, seqHi = 0;
+    for (size_t i = 0; i < numPairs; i++) {
+        const dpx_pair_dev &pd = b->pairs[i];
+        seqLo = std::min(seqLo, (size_t)std::min(pd.refIdx, pd.qryIdx));
+        seqHi = std::max(seqHi, std::max((size_t)pd.refIdx + (size_t)pd.n, (size_t)pd.qryIdx + (size_t)pd.m));
+    }
+    if (seqHi <= seqLo) seqLo = seqHi = 0;
+    for (size_t i = 0; i < numPairs; i++) { b->pairs[i].refIdx -= (int32_t)seqLo; b->pairs[i].qryIdx -= (int32_t)seqLo; }
+    sequences += seqLo;
+    numBytes = seqHi - seqLo;
     CREATE_TRY(hipMalloc((void **)&b->dSeq, std::max<size_t>(numBytes, 16)));
     CREATE_TRY(hipMalloc((void **)&b->dPairs, std::max<size_t>(numPairs, 1) * sizeof(dpx_pair_dev)));
     CREATE_TRY(hipMalloc((void **)&b->dScore, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
@@ -803,10 +815,12 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
     if (!b || pair >= b->numPairs) return DPX_ERR_INVALID;
     if (!b->store) return DPX_ERR_NO_MATRIX;
     if (!b->filled) return DPX_ERR_NOT_FILLED;
-    int rc = bind_device();
-    if (rc != DPX_OK) return rc;
-    rc = run_traceback(b);
-    if (rc != DPX_OK) return rc;
+    if (!b->tbValid) { /* first call after a fill walks every pair of the batch on the device; later calls only copy lines */
+        int rc = bind_device();
+        if (rc != DPX_OK) return rc;
+        rc = run_traceback(b);
+        if (rc != DPX_OK) return rc;
+    }
     const int cap = b->pairs[pair].m + b->pairs[pair].n + 1;
     const int k = b->hTbLen[pair];
     const char *base = b->hTb + b->tbOff[pair];

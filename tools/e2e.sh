@@ -1,18 +1,22 @@
 #!/bin/bash
-# tools/e2e.sh -- end-to-end timing of the batched driver on the headline shape (development aid)
+# tools/e2e.sh [N] [short] -- end-to-end timing of the batched driver (development aid): N pairs of the headline shape
+# (1024x1024), or with "short" of the reference's own dataset shape (reference 100-160, query 80-130)
 set -e
 N=${1:-10000}
+SHAPE=${2:-long}
+BATCH=5000; [ $SHAPE = short ] && BATCH=${3:-20000}
 python - <<PY
 import sys; sys.path.insert(0, ".")
 import dpx_gpu_genomics_project_amd as dpx
-sb = dpx.make_batch($N, 1024, 1024, seed=1)
+from dpx_gpu_genomics_project_amd.synth import make_ragged_batch
+sb = make_ragged_batch($N, 80, 130, 100, 160, seed=6) if "$SHAPE" == "short" else dpx.make_batch($N, 1024, 1024, seed=1)
 dpx.write_pairs_file(sb, "/tmp/e2e_pairs.txt")
 PY
 make -s -C dpx_gpu_genomics_project_amd/hostcpp
 for algo in LSW LNW ANW; do
   EXT=""; OPEN=-2; [ $algo = ANW ] && EXT="-extend -1" && OPEN=-3
-  echo "== $algo $N pairs, print to file"
-  dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT -batch 5000 > /tmp/e2e_out.txt
-  tail -9 /tmp/e2e_out.txt | grep -E "Elapsed|Kernel|Memory|Backtracking|Printing|GCUPS"
+  echo "== $algo $N pairs ($SHAPE), print to file"
+  dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT -batch $BATCH > /tmp/e2e_out.txt
+  tail -9 /tmp/e2e_out.txt | grep -E "Elapsed|Kernel|Memory|Backtracking|Printing|GCUPS|Pars"
   ls -la /tmp/e2e_out.txt | awk '{print "output bytes", $5}'
 done
