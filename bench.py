@@ -38,6 +38,10 @@ WORKLOADS = {
     "anw_1k_1024": ("ANW", 1000, 1024, 1024, 3, -1, -3, -1, 3),
     "lnw_10k_1024": ("LNW", 10000, 1024, 1024, 3, -1, -2, -1, 7),
     "bsw_10k_4096_b128": ("BSW", 10000, 4096, 4096, 3, -1, -2, -1, 4),  # band 128 (BASELINE.json configs[3])
+    # the reference's own dataset shape (configs[0]: short reads, reference 100-160, query 80-130); m = n = 0 -> ragged
+    "lnw_100k_short": ("LNW", 100000, 0, 0, 3, -1, -2, -1, 6),
+    "lsw_100k_short": ("LSW", 100000, 0, 0, 3, -1, -2, -1, 6),
+    "anw_100k_short": ("ANW", 100000, 0, 0, 3, -1, -3, -1, 6),
 }
 BAND = 128
 
@@ -49,7 +53,7 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pairs):
+def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pairs, shape):
     """Time the reference CPU path on a bounded sample (first `budget_pairs` pairs of this rank's batch)."""
     import numpy as np
     from dpx_gpu_genomics_project_amd.synth import SynthBatch, write_pairs_file
@@ -60,7 +64,7 @@ def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pa
     sample = SynthBatch(sb.sequences[:end], sb.pairs[:npairs], sb.m, sb.n)
     ref_o2 = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
     ref_o0 = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    desc = f"first {npairs} pairs of the rank-0 batch ({sb.m}x{sb.n}), fill = init_matrix+score_matrix"
+    desc = f"first {npairs} pairs of the rank-0 batch ({shape}), fill = init_matrix+score_matrix"
     if algo_name == "BSW":
         budget_pairs = min(budget_pairs, 64)  # the banded oracle walks 4096 rows x 255 cells per pair
     npairs = min(budget_pairs, sb.num_pairs)
@@ -140,7 +144,11 @@ def main():
         npairs = args.pairs
     algo = {"LNW": dpx.ALGO_LNW, "LSW": dpx.ALGO_LSW, "ANW": dpx.ALGO_ANW, "BSW": dpx.ALGO_BSW}[algo_name]
     # independent sub-batch per rank (weak scaling): same composition, different seed / pair indices
-    sb = dpx.make_batch(npairs, m, n, seed=seed + 1000 * rank, first_index=rank * npairs)
+    if m == 0:
+        from dpx_gpu_genomics_project_amd.synth import make_ragged_batch
+        sb = make_ragged_batch(npairs, 80, 130, 100, 160, seed=seed + 1000 * rank)
+    else:
+        sb = dpx.make_batch(npairs, m, n, seed=seed + 1000 * rank, first_index=rank * npairs)
     batch = dpx.Batch(algo, sb.sequences, sb.pairs, match, mismatch, gap_open, gap_extend, band=BAND if algo_name == "BSW" else 0)
     info = batch.info()
     # a dedicated (non-null) torch stream is made current: the fill kernel, the HIP events that time it and the
@@ -194,13 +202,18 @@ def main():
     # sanity on results (outside the timed region): a few pairs against the closed-form identical-pair score
     scores, er, ec = batch.results()
     ident = [p for p in range(npairs) if (rank * npairs + p) % 101 == 100][:4]
-    for p in ident:
+    for p in ident if m else []:
         assert scores[p] == match * min(m, n), "identical pair must score match*len"
     if world > 1 and rank == 0:  # the gathered vector must carry every rank's scores in rank order
         assert last is not None and last.numel() == npairs * world
         assert torch.equal(last[:npairs].cpu(), torch.from_numpy(scores))
 
     if rank == 0:
+        shape = f"{m}x{n}" if m else "short-read (reference 100-160 x query 80-130)"
+        # arithmetic type of the kernel the engine picks for this batch (dpx_capi.cpp): equal-shaped LSW/LNW pairs whose
+        # query fits one stripe run two per wave on the packed-int16 pipe (v_pk_*_i16), everything else in int32
+        packed = algo_name in ("LSW", "LNW") and 0 < m <= 1024 and npairs >= 4096 and os.environ.get("DPX_PACKED", "1") != "0"
+        dtype = "int16" if packed else "int32"
         total_cells = info["cells"] * world
         value = total_cells * args.steps / elapsed / 1e9
         achieved = info["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
@@ -214,8 +227,8 @@ def main():
         out = {
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{algo_name} {npairs}-pair {m}x{n} batch per GPU, int16 score matrix written to HBM",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{algo_name} {npairs}-pair {shape} batch per GPU, int16 score matrix written to HBM",
                        "algorithm": algo_name, "pairs_per_gpu": npairs, "query_len": m, "reference_len": n,
                        "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
                        "parallelism": f"{world} rank(s), 1 per GPU, pairs sharded, RCCL gather of int32 scores" if world > 1 else "1 GPU",
@@ -226,7 +239,8 @@ def main():
                          "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, args.cpu_pairs)
+            out["cpu_baseline"] = cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend,
+                                               args.cpu_pairs if m else npairs, shape)
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:

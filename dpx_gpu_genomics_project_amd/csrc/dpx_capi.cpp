@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -112,7 +113,7 @@ struct SlotCache {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-SlotCache g_tbDev, g_tbHost;
+SlotCache g_tbDev, g_tbHost, g_arena;
 
 void *slot_take(SlotCache &c, size_t bytes, size_t *actual) {
     std::lock_guard<std::mutex> lk(c.mu);
@@ -130,16 +131,50 @@ void *slot_take(SlotCache &c, size_t bytes, size_t *actual) {
 void *slot_park(SlotCache &c, void *ptr, size_t bytes) {
     if (!ptr) return nullptr;
     std::lock_guard<std::mutex> lk(c.mu);
-    if (bytes < (1u << 20)) return ptr;
+    if (bytes < (64u << 10)) return ptr;
     void *evict = c.ptr;
     c.ptr = ptr;
     c.bytes = bytes;
     return evict;
 }
 
+/* hipStreamCreate / hipStreamDestroy cost ~2 ms each on this stack: a finished batch parks its (idle) stream */
+struct StreamCache {
+    std::mutex mu;
+    hipStream_t s = nullptr;
+    int device = -1;
+} g_stream;
+
+hipError_t stream_take(hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream.mu);
+        if (g_stream.s && g_stream.device == g_device) { *out = g_stream.s; g_stream.s = nullptr; return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_park(hipStream_t s) {
+    if (!s) return;
+    hipStream_t evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_stream.mu);
+        evict = g_stream.s;
+        g_stream.s = s;
+        g_stream.device = g_device;
+    }
+    if (evict) (void)hipStreamDestroy(evict);
+}
+
 void pool_trim() {
     {
-        void *d = nullptr, *h = nullptr;
+        hipStream_t st = nullptr;
+        { std::lock_guard<std::mutex> lk(g_stream.mu); st = g_stream.s; g_stream.s = nullptr; }
+        if (st) (void)hipStreamDestroy(st);
+    }
+    {
+        void *d = nullptr, *h = nullptr, *ar = nullptr;
+        { std::lock_guard<std::mutex> lk(g_arena.mu); ar = g_arena.ptr; g_arena.ptr = nullptr; g_arena.bytes = 0; }
+        if (ar) (void)hipFree(ar);
         { std::lock_guard<std::mutex> lk(g_tbDev.mu); d = g_tbDev.ptr; g_tbDev.ptr = nullptr; g_tbDev.bytes = 0; }
         { std::lock_guard<std::mutex> lk(g_tbHost.mu); h = g_tbHost.ptr; g_tbHost.ptr = nullptr; g_tbHost.bytes = 0; }
         if (d) (void)hipFree(d);
@@ -155,6 +190,20 @@ void pool_trim() {
     if (stale) (void)hipFree(stale);
 }
 
+} // namespace
+
+namespace {
+/* DPX_TRACE=1: phase timings of dpx_batch_create / destroy on stderr (development aid) */
+struct PhaseTrace {
+    bool on = getenv("DPX_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dpx] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 } // namespace
 
 struct dpx_batch {
@@ -173,6 +222,9 @@ struct dpx_batch {
     char *dSeq = nullptr;
     dpx_pair_dev *dPairs = nullptr;
     int32_t *dOrder = nullptr;
+    char *arena = nullptr;   /* one device allocation behind dSeq, dPairs, dScore/dEndRow/dEndCol, dOrder, dCouples, dTbOff, dTbLen
+                                (parked and reused across batches like the matrix pool: 9 hipMalloc/hipFree pairs per batch otherwise) */
+    size_t arenaCap = 0;
     int16_t *dMat = nullptr;
     int32_t *dScore = nullptr, *dEndRow = nullptr, *dEndCol = nullptr;
     hipStream_t stream = nullptr;     /* the batch's own stream */
@@ -298,21 +350,17 @@ static bool fits_int16(const dpx_params &p, long long m, long long n) {
 
 int dpx_batch_destroy(dpx_batch *b) {
     if (!b) return DPX_OK;
+    PhaseTrace trace;
     if (g_device >= 0) (void)hipSetDevice(g_device);
-    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    (void)hipFree(b->dSeq);
-    (void)hipFree(b->dPairs);
-    (void)hipFree(b->dOrder);
-    (void)hipFree(b->dCouples);
+    /* buffers are parked for the next batch, not freed: nothing of this batch may still be running on them */
+    if (b->lastStream && b->lastStream != b->stream) (void)hipStreamSynchronize(b->lastStream);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); stream_park(b->stream); }
+    if (void *ev = slot_park(g_arena, b->arena, b->arenaCap)) (void)hipFree(ev);
     pool_release(b->dMat, b->matPoolBytes);
-    (void)hipFree(b->dScore);
-    (void)hipFree(b->dEndRow);
-    (void)hipFree(b->dEndCol);
-    (void)hipFree(b->dTbOff);
     if (void *ev = slot_park(g_tbDev, b->dTb, b->dTbCap)) (void)hipFree(ev);
-    (void)hipFree(b->dTbLen);
     if (void *ev = slot_park(g_tbHost, b->hTb, b->hTbCap)) (void)hipHostFree(ev);
     delete b;
+    trace.mark("destroy");
     return DPX_OK;
 }
 
@@ -326,6 +374,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     rc = bind_device();
     if (rc != DPX_OK) return rc;
 
+    PhaseTrace trace;
     dpx_batch *b = new (std::nothrow) dpx_batch();
     if (!b) return DPX_ERR_NOMEM;
     b->prm = *params;
@@ -421,7 +470,10 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (e__ != hipSuccess) { int r__ = hip_fail(e__, #call); dpx_batch_destroy(b); return r__; } \
     } while (0)
 
-    CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    trace.mark("create: validate+geometry");
+    CREATE_TRY(stream_take(&b->stream));
+    trace.mark("create: stream");
+    int32_t *arenaOrder = nullptr, *arenaCouples = nullptr;
     /* only the bytes this batch's pairs touch go to the device (a driver that cuts one big file into batches hands the
      * whole file to every dpx_batch_create): upload [seqLo, seqHi) and rebase the device-side indices */
     size_t seqLo = numBytes, seqHi = 0;
@@ -434,12 +486,27 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     for (size_t i = 0; i < numPairs; i++) { b->pairs[i].refIdx -= (int32_t)seqLo; b->pairs[i].qryIdx -= (int32_t)seqLo; }
     sequences += seqLo;
     numBytes = seqHi - seqLo;
-    CREATE_TRY(hipMalloc((void **)&b->dSeq, std::max<size_t>(numBytes, 16)));
-    CREATE_TRY(hipMalloc((void **)&b->dPairs, std::max<size_t>(numPairs, 1) * sizeof(dpx_pair_dev)));
-    CREATE_TRY(hipMalloc((void **)&b->dScore, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
-    CREATE_TRY(hipMalloc((void **)&b->dEndRow, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
-    CREATE_TRY(hipMalloc((void **)&b->dEndCol, std::max<size_t>(numPairs, 1) * sizeof(int32_t)));
+    {
+        const size_t np1 = std::max<size_t>(numPairs, 1);
+        const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
+        const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
+        const size_t need = szSeq + szPairs + 6 * szI32 + szOff; /* score, endRow, endCol, order, couples, tbLen */
+        if (void *rec = slot_take(g_arena, need, &b->arenaCap)) b->arena = (char *)rec;
+        else { CREATE_TRY(hipMalloc((void **)&b->arena, need)); b->arenaCap = need; }
+        char *q = b->arena;
+        b->dSeq = q;                  q += szSeq;
+        b->dPairs = (dpx_pair_dev *)q; q += szPairs;
+        b->dScore = (int32_t *)q;     q += szI32;
+        b->dEndRow = (int32_t *)q;    q += szI32;
+        b->dEndCol = (int32_t *)q;    q += szI32;
+        b->dOrder = nullptr;          arenaOrder = (int32_t *)q; q += szI32;
+        b->dCouples = nullptr;        arenaCouples = (int32_t *)q; q += szI32;
+        b->dTbLen = (int32_t *)q;     q += szI32;
+        b->dTbOff = (uint64_t *)q;
+    }
+    trace.mark("create: arena");
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
+    trace.mark("create: H2D sequences");
     /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
     std::vector<int32_t> singles, couples;
     size_t numQuad8 = 0;
@@ -505,7 +572,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->packed = !couples.empty();
     }
     if (b->packed || b->quad) {
-        CREATE_TRY(hipMalloc((void **)&b->dCouples, couples.size() * sizeof(int32_t)));
+        b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     } else if (ragged) {
         singles.resize(numPairs);
@@ -515,7 +582,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         std::stable_sort(singles.begin(), singles.end(), [&](int32_t x, int32_t y) {
             return (uint64_t)b->pairs[x].m * b->pairs[x].n > (uint64_t)b->pairs[y].m * b->pairs[y].n;
         });
-        CREATE_TRY(hipMalloc((void **)&b->dOrder, singles.size() * sizeof(int32_t)));
+        b->dOrder = arenaOrder;
         CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     const size_t numSingles = (b->packed || b->quad) ? singles.size() : numPairs;
@@ -606,12 +673,14 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         }
         b->matElems = off;
     }
+    trace.mark("create: launch lists+placement");
     if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
     if (b->store && b->matElems) {
         void *pool = nullptr;
         CREATE_TRY(pool_alloc(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
         b->dMat = (int16_t *)pool;
     }
+    trace.mark("create: H2D pairs+matrix pool");
 #undef CREATE_TRY
 
     dpx_fill_args &a = b->args;
@@ -789,11 +858,9 @@ static int run_traceback(dpx_batch *b) {
         uint64_t off = 0;
         for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)(b->pairs[i].m + b->pairs[i].n + 1); }
         b->tbOff[np] = off;
-        HIP_TRY(hipMalloc((void **)&b->dTbOff, (np + 1) * sizeof(uint64_t)));
         const size_t need = (size_t)std::max<uint64_t>(off, 16);
         if (void *rec = slot_take(g_tbDev, need, &b->dTbCap)) b->dTb = (char *)rec;
         else { HIP_TRY(hipMalloc((void **)&b->dTb, need)); b->dTbCap = need; }
-        HIP_TRY(hipMalloc((void **)&b->dTbLen, std::max<size_t>(np, 1) * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         b->hTbBytes = off;
         if (void *rec = slot_take(g_tbHost, need, &b->hTbCap)) b->hTb = (char *)rec;
