@@ -1,0 +1,45 @@
+#!/bin/bash
+# tools/profile_round.sh <tag> [workload] -- the evidence bench.py's roofline object rests on, for one workload, on the GPU box:
+#   1. bench.py                                   -> <tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats           -> <tag>_kernel_stats.csv (+ bench line under the profiler)
+#   3. rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE, SEPARATE passes -> <tag>_pmc.json
+#      (KiB counters; FETCH_SIZE doubled for gfx950 per MI355X_MICROARCH.md; per fill-kernel launch)
+# Output under gpurun_out/profile/; copy what should be judged into profiles/rNN/.
+set -u
+TAG=$1; WL=${2:-lsw_10k_1024}
+REPO=$(pwd); OUT=$REPO/gpurun_out/profile; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $REPO
+python3 bench.py --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o st -- python3 bench.py --workload $WL --no-cpu-baseline \
+    > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err || exit 1
+cp $(find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+for c in WRITE_SIZE FETCH_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_$c -o pm -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline \
+      > $OUT/${TAG}_$c.log 2>&1 || exit 1
+done
+python3 - $OUT $TAG $WL <<'PY'
+import csv, glob, json, sys
+out, tag, wl = sys.argv[1:4]
+def per_launch(counter):
+    f = glob.glob(f"{out}/{tag}_{counter}/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if r["Counter_Name"] != counter or not ("k_linear" in k or "k_affine" in k or "k_banded" in k):
+            continue
+        acc.setdefault(r["Dispatch_Id"], [k, 0.0])[1] += float(r["Counter_Value"])
+    names = sorted({v[0] for v in acc.values()})
+    # a batch may need more than one fill kernel per step (couples + leftovers, 8-row + 16-row quad classes): sum per step
+    steps = 4  # --steps 3 --warmup 1
+    return sum(v[1] for v in acc.values()) / steps, names
+w, names = per_launch("WRITE_SIZE")
+f, _ = per_launch("FETCH_SIZE")
+res = {"workload": wl, "fill_kernels": names, "WRITE_SIZE_KB_per_fill": w, "FETCH_SIZE_KB_per_fill": f,
+       "hbm_bytes_per_fill": w * 1024 + 2 * f * 1024,
+       "note": "rocprofv3 --kernel-trace --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes over bench.py --steps 3 --warmup 1; "
+               "counters are KiB; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads, MI355X_MICROARCH.md)"}
+json.dump(res, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
+print(json.dumps(res))
+PY
+head -5 $OUT/${TAG}_kernel_stats.csv
+cat $OUT/${TAG}_bench.json
