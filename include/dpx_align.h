@@ -102,7 +102,9 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
 /* Launch the DP fill for every pair of the batch on `stream` (a hipStream_t, or NULL for the batch's own
  * stream).  Asynchronous.  Replaces `needleman_wunsch_kernel<<<BATCH/2,32,smem>>>` (V19.cu:536),
  * `smith_waterman_kernel<<<1,32>>>` (cuda/LinearSmithWaterman.cu:263) and
- * `affine_needleman_wunsch_kernel<<<1,32>>>` (cuda/AffineNeedlemanWunsch.cu:338).  May be called repeatedly. */
+ * `affine_needleman_wunsch_kernel<<<1,32>>>` (cuda/AffineNeedlemanWunsch.cu:338).  May be called repeatedly.
+ * A caller-owned stream must stay valid until the batch has been synchronised or destroyed: dpx_batch_destroy()
+ * waits on the stream of the last fill before it parks the batch's buffers for reuse by the next batch. */
 int dpx_batch_fill(dpx_batch *b, void *stream);
 
 /* Run `repeats` fills back-to-back and return the mean device time of one fill in microseconds, measured with

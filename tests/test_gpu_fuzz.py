@@ -33,13 +33,21 @@ def random_batch(rng, count, max_len, alphabet):
 WEIGHTS = [(3, -1, -2, -1), (1, -1, -1, -1), (2, -3, 0, -1), (0, 0, 0, 0), (5, 2, -4, -2), (1, -2, 1, -3), (7, -5, -9, 1)]
 
 
+@pytest.mark.parametrize("seed", [4, 5])
+@pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
+def test_fuzz_quad_kernels(gpu, algo, seed, monkeypatch):
+    """The same fuzz through the four-pairs-per-wave kernels (queries <= 256 rows; DPX_QUAD=1 forces them on small batches)."""
+    monkeypatch.setenv("DPX_QUAD", "1")
+    test_fuzz(gpu, algo, seed, max_lens=(70, 140, 256))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 @pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW", "BSW"])
-def test_fuzz(gpu, algo, seed):
+def test_fuzz(gpu, algo, seed, max_lens=(70, 140, 300)):
     rng = np.random.default_rng(1000 * seed + len(algo) + ord(algo[0]))
     for wi, w in enumerate(WEIGHTS):
         alphabet = [np.array([48, 49, 50, 51], np.uint8), np.arange(256, dtype=np.uint8), np.array([0, 255], np.uint8)][wi % 3]
-        sb = random_batch(rng, 24, [70, 140, 300][(wi + seed) % 3], alphabet)
+        sb = random_batch(rng, 24, max_lens[(wi + seed) % 3], alphabet)
         band = int(rng.integers(1, 80))
         code = {"LNW": gpu.ALGO_LNW, "LSW": gpu.ALGO_LSW, "ANW": gpu.ALGO_ANW, "BSW": gpu.ALGO_BSW}[algo]
         with gpu.Batch(code, sb.sequences, sb.pairs, w[0], w[1], w[2], w[3], band=band if algo == "BSW" else 0) as b:
