@@ -518,8 +518,10 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
      * the chip with a quarter of the waves run four pairs per wave, one per 16-lane DPP row; DPX_QUAD=0/1 overrides. */
     const bool linearAlgo = kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW;
     const bool quadAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
-    bool useQuad = quadAlgo && b->maxM <= 256 && b->maxM > 0 && numPairs >= 8192;
-    if (const char *env = getenv("DPX_QUAD")) useQuad = atoi(env) != 0 && quadAlgo && b->maxM <= 256 && b->maxM > 0;
+    /* (four staged references per wave: keep the quad path to references that leave the LDS request small) */
+    const bool quadShape = quadAlgo && b->maxM <= 256 && b->maxM > 0 && b->maxN <= 2048;
+    bool useQuad = quadShape && numPairs >= 8192; /* measured crossover on short reads (tools/quad_threshold.py) */
+    if (const char *env = getenv("DPX_QUAD")) useQuad = atoi(env) != 0 && quadShape;
     if (useQuad) {
         b->R = 8; /* empty pairs, if any, run on the one-pair-per-wave kernel at this tile height (they have no cells) */
         for (size_t i = 0; i < numPairs; i++) {
