@@ -408,27 +408,31 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             const unsigned char *rp = refl + 64 - lane; /* rp[t] = reference character of column j = t - lane + 1 */
             int rcN = rp[0];
             int e0N = edge[1];
-#define DPX_LIN_STEP(MASKED_, WHOLE_, HASROWS_)                                                                        \
+#define DPX_LIN_STEP(T_, MASKED_, WHOLE_, HASROWS_)                                                                    \
             {                                                                                                         \
                 const int rc = rcN, e0 = e0N;                                                                         \
-                rcN = rp[t + 1];                                                                                      \
-                e0N = edge[min(t + 2, n + 1)];                                                                        \
-                lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
-                                                           hasNext, tile + (size_t)t * cs, storeLanes);              \
+                rcN = rp[(T_) + 1];                                                                                   \
+                e0N = edge[min((T_) + 2, n + 1)];                                                                     \
+                lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, (T_), lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
+                                                           hasNext, tile + (size_t)(T_) * cs, storeLanes);           \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
             const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
             if (S == 1) { /* the ramp chunks belong to this stripe alone: store them whole */
                 if (fast) {
                     int t = 0;
-                    for (; t < 63; t++) DPX_LIN_STEP(true, true, true)
-                    for (; t < n; t++) DPX_LIN_STEP(false, true, true)
-                    for (; t < W; t++) DPX_LIN_STEP(true, true, true)
+                    for (; t < 63; t++) DPX_LIN_STEP(t, true, true, true)
+                    for (; t + 1 < n; t += 2) { /* two steps per trip: the left/diagonal registers swap roles instead of moving */
+                        DPX_LIN_STEP(t, false, true, true)
+                        DPX_LIN_STEP(t + 1, false, true, true)
+                    }
+                    for (; t < n; t++) DPX_LIN_STEP(t, false, true, true)
+                    for (; t < W; t++) DPX_LIN_STEP(t, true, true, true)
                 } else {
-                    for (int t = 0; t < W; t++) DPX_LIN_STEP(true, true, laneHasRows)
+                    for (int t = 0; t < W; t++) DPX_LIN_STEP(t, true, true, laneHasRows)
                 }
             } else { /* several stripes of a short reference share their ramp chunks: masked stores there */
-                for (int t = 0; t < W; t++) DPX_LIN_STEP(true, false, laneHasRows)
+                for (int t = 0; t < W; t++) DPX_LIN_STEP(t, true, false, laneHasRows)
             }
 #undef DPX_LIN_STEP
             if constexpr (LOCAL) lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
     const unsigned char *rp = refl + 16 - l; /* rp[t] = reference character of column j = t - l + 1 */
     int rcN = rp[0];
     const int steps = nmax + 15;
-    for (int t = 0; t < steps; t++) {
+    auto quad_step = [&](const int t) {
         const int j = t - l + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
@@ -539,6 +543,14 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
                 }
             }
         }
+    };
+    {
+        int t = 0;
+        for (; t + 1 < steps; t += 2) { /* two steps per trip (registers swap roles instead of moving, keys fold with max3) */
+            quad_step(t);
+            quad_step(t + 1);
+        }
+        if (t < steps) quad_step(t);
     }
     if (!has) return;
     if constexpr (LOCAL) {
@@ -1152,6 +1164,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
                 if (fast) {
                     int t = 0;
                     for (; t < 63; t++) DPX_AFF_STEP(true, true, true)
+                    for (; t + 1 < n;) { DPX_AFF_STEP(false, true, true) t++; DPX_AFF_STEP(false, true, true) t++; } /* two steps per trip */
                     for (; t < n; t++) DPX_AFF_STEP(false, true, true)
                     for (; t < W; t++) DPX_AFF_STEP(true, true, true)
                 } else {
@@ -1160,6 +1173,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
             } else if (fast) { /* stripes share their ramp chunks: masked stores on the ramps */
                 int t = 0;
                 for (; t < 63; t++) DPX_AFF_STEP(true, false, true)
+                for (; t + 1 < n;) { DPX_AFF_STEP(false, false, true) t++; DPX_AFF_STEP(false, false, true) t++; }
                 for (; t < n; t++) DPX_AFF_STEP(false, false, true)
                 for (; t < W; t++) DPX_AFF_STEP(true, false, true)
             } else {
@@ -1223,7 +1237,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill
     const unsigned char *rp = refl + 16 - l;
     int rcN = rp[0];
     const int steps = nmax + 15;
-    for (int t = 0; t < steps; t++) {
+    auto quad_step = [&](const int t) {
         const int j = t - l + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
@@ -1248,6 +1262,14 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill
                 }
             }
         }
+    };
+    {
+        int t = 0;
+        for (; t + 1 < steps; t += 2) {
+            quad_step(t);
+            quad_step(t + 1);
+        }
+        if (t < steps) quad_step(t);
     }
     if (!has) return;
     const int lm = (m - 1) / R, rm = (m - 1) % R;
