@@ -744,7 +744,6 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
 }
 
 static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
-    const bool sw = b->kernelAlgo == DPX_ALGO_LSW && b->store;
     if (b->packed) {
         hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
         if (e != hipSuccess) return e;
@@ -757,7 +756,6 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     }
     if (b->streamed) return dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
     hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
-    if (e == hipSuccess && sw && DPX_SW_RESCAN) e = dpx_launch_sw_locate(b->args, b->R, s);
     return e;
 }
 

@@ -16,11 +16,6 @@
 /* one wave per pair; DPX_FILL_THREADS/64 independent waves share a workgroup (no barriers between them) */
 #define DPX_FILL_THREADS 256
 
-/* SW with matrices: 1 = track packed row maxima in the fill and finish the start cell with k_sw_locate,
- * 0 = track (score, column) keys in the fill (no follow-up launch) */
-#ifndef DPX_SW_RESCAN
-#define DPX_SW_RESCAN 0 /* keys measured faster: the locate launch costs more than the 12 VALU ops per step it saves */
-#endif
 
 typedef struct dpx_fill_args {
     const char *seq;            /* flat sequence bytes (device copy of parseInput's buffer) */
@@ -43,7 +38,6 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
 hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
-hipError_t dpx_launch_sw_locate(const dpx_fill_args &a, int R, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream);
 hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, const uint64_t *tbOff,

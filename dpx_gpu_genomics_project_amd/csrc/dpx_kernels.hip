@@ -95,9 +95,7 @@ template <int R, bool LOCAL>
 struct LinState {
     int Hl[R];        /* H[row][j-1] of the lane's R rows (the "left" values, then overwritten by H[row][j]) */
     int qc[R];        /* query characters of the lane's rows */
-    unsigned key[R];  /* SW, score-only: per-row running max of (H << 16 | 0xFFFF - j): max score, then smallest column */
-    unsigned rmaxP[(R + 1) / 2]; /* SW with matrices: running row maxima, two rows per dword (v_pk_max_u16 on the
-                                    dwords packed for the store anyway); the column is re-read from the matrix at the end */
+    unsigned key[R];  /* SW: per-row running max of (H << 16 | 0xFFFF - j): max score, then smallest column */
     int dtop;         /* H[row0][j-1]: diagonal of the lane's top row */
 };
 
@@ -138,14 +136,11 @@ __device__ __forceinline__ void lin_cells(LinState<R, LOCAL> &st, const int upin
     st.dtop = upin;
 }
 
-/* pack the lane's R scores into R/2 dwords (the store format); SW additionally folds them into the packed row maxima */
-template <int R, bool LOCAL, bool TRACK>
+/* pack the lane's R scores into R/2 dwords (the store format) */
+template <int R, bool LOCAL>
 __device__ __forceinline__ void lin_pack(LinState<R, LOCAL> &st, uint32_t (&w)[(R + 1) / 2]) {
 #pragma unroll
-    for (int q = 0; q < R / 2; q++) {
-        w[q] = pack_lo16(st.Hl[2 * q], st.Hl[2 * q + 1]);
-        if constexpr (LOCAL && TRACK) st.rmaxP[q] = as_u32(dpx::pk_max(as_u16x2(st.rmaxP[q]), as_u16x2(w[q])));
-    }
+    for (int q = 0; q < R / 2; q++) w[q] = pack_lo16(st.Hl[2 * q], st.Hl[2 * q + 1]);
 }
 
 template <int R>
@@ -166,14 +161,12 @@ __device__ __forceinline__ void store_words(int16_t *dst, const uint32_t (&w)[(R
 
 /* SW: fold the finished stripe's per-row keys into the lane's best (rows ascend with r and with the stripe index,
  * so a strict '>' keeps the first row holding the lane's maximum) */
-template <int R, bool LOCAL, bool KEYS>
+template <int R, bool LOCAL>
 __device__ __forceinline__ void lin_fold_keys(const LinState<R, LOCAL> &st, const int row0, const int nrows, int &bestv,
                                               int &bestrow, int &bestcol) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int hv, col = 0;
-        if constexpr (KEYS) { hv = (int)(st.key[r] >> 16); col = 0xFFFF - (int)(st.key[r] & 0xFFFFu); }
-        else hv = (int)((st.rmaxP[r / 2] >> (16 * (r & 1))) & 0xFFFFu);
+        const int hv = (int)(st.key[r] >> 16), col = 0xFFFF - (int)(st.key[r] & 0xFFFFu);
         if (r < nrows && hv > bestv) {
             bestv = hv;
             bestrow = row0 + 1 + r;
@@ -182,68 +175,8 @@ __device__ __forceinline__ void lin_fold_keys(const LinState<R, LOCAL> &st, cons
     }
 }
 
-/* A wave re-reading int16 cells it stored itself.  No fence (an agent-scope release/acquire costs ~1 ms per fill when
- * 10k waves each issue one): the load bypasses this CU's L1 (`sc1`), is served by the XCD's L2 -- where this wave's
- * own stores landed, and they are drained first by the caller (`s_waitcnt vmcnt(0)`) -- and is waited for inside
- * the same asm statement, because hipcc does not count asm loads. */
-__device__ __forceinline__ int load_own_i16(const int16_t *p) {
-    int v;
-    asm volatile("global_load_sshort %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-/* first column of row i (1-based) whose stored score equals `want`; whole wave cooperates; 0 if none */
-template <int R>
-__device__ __forceinline__ int first_col_equal(const int16_t *Hp, size_t cs, int i, int n, int want, int lane) {
-    const int i0 = i - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
-    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + dpx_tile_off(R, 0, l, r); /* column 1 */
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's stores have reached the L2 */
-    for (int j0 = 1; j0 <= n; j0 += 64) {
-        const int j = j0 + lane;
-        const int v = (j <= n) ? load_own_i16(Hp + rowBase + (size_t)(j - 1) * cs) : -32768;
-        const unsigned long long hit = __ballot(v == want);
-        if (hit) return j0 + __ffsll((long long)hit) - 1;
-    }
-    return 0;
-}
-
-/* SW start-cell completion.  The fill kernels that track packed row maxima know the maximum and its first row when
- * they finish, but not its first column; this follow-up launch (one wave per pair, same stream) reads that single row
- * back -- 2 bytes x n per pair -- and fills in endCol.  Doing the re-read inside the fill wave instead costs 10 %: the
- * wave must first drain its own stores and then sits on its SIMD slot through a chain of dependent loads. */
-template <int R>
-__global__ void __launch_bounds__(256) k_sw_locate(const dpx_fill_args a) {
-    const int lane = threadIdx.x & 63;
-    int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (p >= a.numPairs) return;
-    if (a.order) p = a.order[p];
-    const int want = a.score[p], row = a.endRow[p];
-    if (want <= 0 || row <= 0) return; /* score 0: (0, 0) already written */
-    const dpx_pair_dev pr = a.pairs[p];
-    const int n = pr.n, i0 = row - 1, k = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
-    const int16_t *Hp = a.mat + pr.matOff;
-    const size_t cs = pr.chunkStride;
-    const size_t rowBase = ((size_t)k * (size_t)n + (size_t)l) * cs + dpx_tile_off(R, 0, l, r); /* column 1 */
-    for (int j0 = 1; j0 <= n; j0 += 256) { /* four independent loads in flight per lane */
-        int v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int j = j0 + 64 * q + lane;
-            v[q] = (j <= n) ? (int)Hp[rowBase + (size_t)(j - 1) * cs] : -32768;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long hit = __ballot(v[q] == want);
-            if (hit) {
-                if (lane == 0) a.endCol[p] = j0 + 64 * q + __ffsll((long long)hit) - 1;
-                return;
-            }
-        }
-    }
-}
-
 /* WHOLE: store for every lane (the chunk is private to this stripe); otherwise only lanes on a real cell store.
- * With matrices (STORE) SW tracks packed row maxima, score-only SW tracks (score, column) keys. */
+ * SW tracks per-row (score, column) keys in registers, so the start cell needs no second pass over the matrix. */
 template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
                                          const bool laneHasRows, const int match, const int mismatch, const int gap,
@@ -256,14 +189,14 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
     if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
     uint32_t w[(R + 1) / 2];
     if (active) {
-        lin_cells<R, LOCAL, !(STORE && DPX_SW_RESCAN)>(st, upin, rc, j, match, mismatch, gap);
+        lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
         if (writeEdge && lane == 63) edge[j] = (int16_t)st.Hl[R - 1];
         if constexpr (STORE) {
-            lin_pack<R, LOCAL, DPX_SW_RESCAN != 0>(st, w);
+            lin_pack<R, LOCAL>(st, w);
             if constexpr (MASKED && !WHOLE) store_words<R>(tileDst, w);
         }
     } else if constexpr (STORE) {
-        lin_pack<R, LOCAL, false>(st, w);
+        lin_pack<R, LOCAL>(st, w);
     }
     /* Every lane stores, also lanes that are not on a real cell during the skew ramps: the wave then always writes
      * its whole 64*R*2-byte chunk.  Partial chunks (masked stores) measured ~2.5x the cost of full ones -- a chunk
@@ -277,10 +210,6 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
 template <int R, bool LOCAL, bool STORE>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    /* How SW finds its start cell (see LinState): score-only fills track (score, column) keys (2 VALU ops per cell);
-     * fills that write the matrix track packed row maxima (12 fewer ops per step at R = 8) and k_sw_locate re-reads
-     * the winning row afterwards. */
-    constexpr bool KEYS = !(STORE && DPX_SW_RESCAN);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* wave-uniform: everything per-pair lives in SGPRs */
@@ -313,8 +242,6 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
 
     int bestv = 0, bestrow = 0, bestcol = 0;
     LinState<R, LOCAL> st;
-#pragma unroll
-    for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
 
     if (STORE && S >= 2 && n >= 128) { /* (score-only fills are VALU-bound: the plain striped loop is leaner there) */
         /* ---------- rolling schedule: a lane that finishes column n of its stripe starts column 1 of the next one
@@ -349,9 +276,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             const int upin = wave_shr1(st.Hl[R - 1], e0);
             if (sw) { /* stripe switch (one lane per step for 64 steps around each stripe boundary) */
                 if constexpr (LOCAL) {
-                    lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
-#pragma unroll
-                    for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
+                    lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
                 }
                 row0 += 64 * R;
                 nrows = min(max(m - row0, 0), R);
@@ -365,11 +290,11 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             }
             uint32_t w[(R + 1) / 2];
             if (jl >= 1 && kl < S && nrows > 0) {
-                lin_cells<R, LOCAL, KEYS>(st, upin, rc, jl, match, mismatch, gap);
+                lin_cells<R, LOCAL, true>(st, upin, rc, jl, match, mismatch, gap);
                 if (lane == 63 && kl + 1 < S) edge[jl] = (int16_t)st.Hl[R - 1];
-                if constexpr (STORE) lin_pack<R, LOCAL, !KEYS>(st, w);
+                if constexpr (STORE) lin_pack<R, LOCAL>(st, w);
             } else if constexpr (STORE) {
-                lin_pack<R, LOCAL, false>(st, w);
+                lin_pack<R, LOCAL>(st, w);
             }
             if constexpr (STORE) store_words<R>(tile + (size_t)T * cs, w); /* whole chunk, every step */
             sw = false;
@@ -382,7 +307,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             roll_step(T + 1);
         }
         if (T < total) roll_step(T);
-        if constexpr (LOCAL) lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
+        if constexpr (LOCAL) lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
     } else {
         /* ---------- striped schedule (single stripe, or references too short to roll) ---------- */
         const int W = n + 63;
@@ -398,8 +323,6 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
                 st.key[r] = 0u;
             }
-#pragma unroll
-            for (int q = 0; q < (R + 1) / 2; q++) st.rmaxP[q] = 0u;
             st.dtop = LOCAL ? 0 : row0 * gap;
             int16_t *tile = Hp + (size_t)k * (size_t)n * cs + (size_t)lane * (R < 8 ? R : 8);
 
@@ -435,7 +358,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 for (int t = 0; t < W; t++) DPX_LIN_STEP(t, true, false, laneHasRows)
             }
 #undef DPX_LIN_STEP
-            if constexpr (LOCAL) lin_fold_keys<R, LOCAL, KEYS>(st, row0, nrows, bestv, bestrow, bestcol);
+            if constexpr (LOCAL) lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
         }
     }
 
@@ -444,17 +367,12 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
          * max score, then smallest row; then the smallest column of that row */
         const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
         const unsigned long long top = wave_max_u64(mine);
-        const int topv = (int)(top >> 32), toprow = 0x7FFFFFFF - (int)(top & 0xFFFFFFFFu);
-        if (topv == 0) {
+        if ((int)(top >> 32) == 0) {
             if (lane == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
-        } else if constexpr (KEYS) {
-            if (mine == top) { /* rows are unique per lane, so exactly one lane matches; it holds the row's first column */
-                a.score[p] = bestv;
-                a.endRow[p] = bestrow;
-                a.endCol[p] = bestcol;
-            }
-        } else {
-            if (lane == 0) { a.score[p] = topv; a.endRow[p] = toprow; a.endCol[p] = 0; } /* column: k_sw_locate */
+        } else if (mine == top) { /* rows are unique per lane, so exactly one lane matches; it holds the row's first column */
+            a.score[p] = bestv;
+            a.endRow[p] = bestrow;
+            a.endCol[p] = bestcol;
         }
     } else {
         /* score = H[m][n] (LinearNeedlemanWunsch.cpp:176): after the last stripe Hl[] holds column n */
@@ -530,7 +448,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
         if constexpr (STORE) {
             if (has && t < n + 15 && l < storeLanes) { /* whole chunks of this row's pair while it is running */
                 uint32_t wd[(R + 1) / 2];
-                lin_pack<R, LOCAL, false>(st, wd);
+                lin_pack<R, LOCAL>(st, wd);
                 int16_t *dst = tile + (size_t)t * cs;
                 if constexpr (R <= 4) {
                     store_words<R>(dst, wd);
@@ -555,7 +473,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
     if (!has) return;
     if constexpr (LOCAL) {
         int bestv = 0, bestrow = 0, bestcol = 0;
-        lin_fold_keys<R, LOCAL, true>(st, row0, nrows, bestv, bestrow, bestcol);
+        lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
         const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
         unsigned long long top = mine;
 #pragma unroll
@@ -669,7 +587,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
         }
         const int upin = wave_shr1(st.Hl[R - 1], e0); /* before a switching lane resets its registers */
         if (sw) {
-            if constexpr (LOCAL) lin_fold_keys<R, LOCAL, true>(st, row0, nrows, bestv, bestrow, bestcol);
+            if constexpr (LOCAL) lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
             if (newPair) { /* this lane has finished pair ol-1 */
                 if constexpr (LOCAL) {
                     dv = bestv; dr = bestrow; dc = bestcol;
@@ -699,7 +617,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
         }
         {
             uint32_t w[(R + 1) / 2];
-            lin_pack<R, LOCAL, false>(st, w);
+            lin_pack<R, LOCAL>(st, w);
             store_words<R>(tile + (size_t)T * cs, w); /* chunk T of the stream, whole, every step */
         }
         sw = false;
@@ -718,7 +636,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
                 int fv = dv, fr = dr, fc = dc;
                 if (lane == 63) {
                     int bv = bestv, br = bestrow, bc = bestcol;
-                    lin_fold_keys<R, LOCAL, true>(st, row0, nrows, bv, br, bc);
+                    lin_fold_keys<R, LOCAL>(st, row0, nrows, bv, br, bc);
                     fv = bv; fr = br; fc = bc;
                 }
                 const unsigned long long mine = ((unsigned long long)(unsigned)fv << 32) | (unsigned)(0x7FFFFFFF - fr);
@@ -755,8 +673,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
  * v_pk_max_i16 / v_pk_add_i16.  One DPP move carries both pairs to the next lane.  Both pairs must have the same
  * (m, n); the host couples equal-shaped pairs and sends leftovers to k_linear_fill.  Matrices are written in the
  * same per-pair wavefront-tiled layout, so export and traceback do not care which kernel filled a pair.
- * SW start cell: the loop only keeps a packed per-row running maximum; the (first row, first column) of the maximum
- * is resolved afterwards by re-reading that single row of the matrix this wave just wrote.
+ * SW start cell: tracked exactly in the loop, per half: a packed running row maximum and the column at which it was
+ * first reached (v_pk_max_u16 / v_pk_sub_u16 / v_pk_min_u16 / v_pk_sub_u16 / v_bfi_b32, see PkState).
  * ===================================================================================================== */
 template <int R>
 struct PkState {
@@ -1779,18 +1697,6 @@ hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_
 }
 
 /* SW start-cell completion for pairs filled by a row-maxima kernel; a.order / a.numPairs select the pairs */
-hipError_t dpx_launch_sw_locate(const dpx_fill_args &a, int R, hipStream_t stream) {
-    if (a.numPairs <= 0) return hipSuccess;
-    dim3 grid((unsigned)((a.numPairs + 3) / 4));
-    switch (R) {
-    case 2: hipLaunchKernelGGL(k_sw_locate<2>, grid, dim3(256), 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(k_sw_locate<4>, grid, dim3(256), 0, stream, a); break;
-    case 8: hipLaunchKernelGGL(k_sw_locate<8>, grid, dim3(256), 0, stream, a); break;
-    case 16: hipLaunchKernelGGL(k_sw_locate<16>, grid, dim3(256), 0, stream, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
 
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream) {
