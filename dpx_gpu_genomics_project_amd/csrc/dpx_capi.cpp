@@ -16,6 +16,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dpx_kernels.h"
@@ -49,145 +50,141 @@ int bind_device() {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-/* The matrix pool is by far the largest allocation (22 GB for the headline batch) and hipMalloc/hipFree of that size
- * cost 50-1000 ms -- the "memory management" slice that dominated the reference's V12 profile (187 of 440 ms) and that
- * it attacked by pooling (V9) and sizing once (V14).  Batched drivers create same-sized batches back to back, so the
- * most recently released pool is parked here and handed to the next batch that fits. */
-struct PoolCache {
-    std::mutex mu;
-    void *ptr = nullptr;
-    size_t bytes = 0;
-    int device = -1;
-} g_pool;
+/* Parked buffers.  The matrix pool is by far the largest allocation (22 GB for the headline batch) and hipMalloc/hipFree
+ * of that size cost 50-1000 ms -- the "memory management" slice that dominated the reference's V12 profile (187 of 440 ms)
+ * and that it attacked by pooling (V9) and sizing once (V14); pinning ~70 MB of host memory costs ~10 ms; and even the
+ * small calls add up when the reference's main.cpp aligns one pair per call from 20 threads.  So nothing a batch
+ * allocates is freed when the batch goes away: buffers are parked per kind and handed to the next batch that fits
+ * (batched drivers create same-sized batches back to back; the class-per-pair drivers create thousands of tiny ones). */
+class BufCache {
+public:
+    enum Kind { Device, PinnedHost };
+    BufCache(Kind kind, size_t maxEntries, size_t maxBytes) : kind_(kind), maxEntries_(maxEntries), maxBytes_(maxBytes) {}
 
-hipError_t pool_alloc(void **out, size_t bytes, size_t *actual) {
-    *actual = bytes;
+    /* a parked buffer of [need, 1.5 * need + 1 MiB], else a fresh allocation (after an out-of-memory: drop everything
+     * that is parked anywhere and retry once) */
+    hipError_t take(void **out, size_t need, size_t *actual);
+    void park(void *ptr, size_t bytes);
+    void drain();
+
+private:
+    struct Entry { void *ptr; size_t bytes; int device; };
+    hipError_t raw_alloc(void **out, size_t bytes) const {
+        return kind_ == Device ? hipMalloc(out, bytes) : hipHostMalloc(out, bytes, hipHostMallocDefault);
+    }
+    void raw_free(void *p) const { if (p) (void)(kind_ == Device ? hipFree(p) : hipHostFree(p)); }
+    const Kind kind_;
+    const size_t maxEntries_, maxBytes_;
+    std::mutex mu_;
+    std::vector<Entry> parked_; /* oldest first */
+    size_t total_ = 0;
+};
+
+void trim_all_caches();
+
+hipError_t BufCache::take(void **out, size_t need, size_t *actual) {
     {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (g_pool.ptr && g_pool.device == g_device && g_pool.bytes >= bytes && g_pool.bytes <= bytes + bytes / 2 + (1u << 20)) {
-            *out = g_pool.ptr;
-            *actual = g_pool.bytes;
-            g_pool.ptr = nullptr;
-            g_pool.bytes = 0;
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t best = parked_.size();
+        for (size_t i = 0; i < parked_.size(); i++) {
+            const Entry &e = parked_[i];
+            if (e.device != g_device || e.bytes < need || e.bytes > need + need / 2 + (1u << 20)) continue;
+            if (best == parked_.size() || e.bytes < parked_[best].bytes) best = i;
+        }
+        if (best != parked_.size()) {
+            *out = parked_[best].ptr;
+            *actual = parked_[best].bytes;
+            total_ -= parked_[best].bytes;
+            parked_.erase(parked_.begin() + (long)best);
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory) { /* give the parked pool back and retry once */
-        void *stale = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(g_pool.mu);
-            stale = g_pool.ptr;
-            g_pool.ptr = nullptr;
-            g_pool.bytes = 0;
-        }
-        if (stale) {
-            (void)hipGetLastError();
-            (void)hipFree(stale);
-            e = hipMalloc(out, bytes);
-        }
+    *actual = need;
+    hipError_t e = raw_alloc(out, need);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        trim_all_caches();
+        e = raw_alloc(out, need);
     }
     return e;
 }
 
-void pool_release(void *ptr, size_t bytes) {
+void BufCache::park(void *ptr, size_t bytes) {
     if (!ptr) return;
-    void *evict = nullptr;
+    std::vector<void *> evicted;
     {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (bytes >= (64u << 20) && g_device >= 0) { /* only large pools are worth parking */
-            evict = g_pool.ptr;
-            g_pool.ptr = ptr;
-            g_pool.bytes = bytes;
-            g_pool.device = g_device;
+        std::lock_guard<std::mutex> lk(mu_);
+        if (g_device < 0 || bytes > maxBytes_) {
+            evicted.push_back(ptr);
         } else {
-            evict = ptr;
+            const size_t big = (size_t)1 << 30; /* at most one parked buffer of a GiB or more */
+            for (size_t i = 0; i < parked_.size();) {
+                const bool drop = (bytes >= big && parked_[i].bytes >= big) || parked_[i].device != g_device;
+                if (drop) { evicted.push_back(parked_[i].ptr); total_ -= parked_[i].bytes; parked_.erase(parked_.begin() + (long)i); }
+                else i++;
+            }
+            while (!parked_.empty() && (parked_.size() >= maxEntries_ || total_ + bytes > maxBytes_)) {
+                evicted.push_back(parked_.front().ptr);
+                total_ -= parked_.front().bytes;
+                parked_.erase(parked_.begin());
+            }
+            parked_.push_back(Entry{ptr, bytes, g_device});
+            total_ += bytes;
         }
     }
-    if (evict) (void)hipFree(evict);
+    for (void *p : evicted) raw_free(p);
 }
 
-/* the same parking trick for the traceback line buffers (device + pinned host mirror): pinning ~70 MB costs ~10 ms */
-struct SlotCache {
-    std::mutex mu;
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
-SlotCache g_tbDev, g_tbHost, g_arena;
-
-void *slot_take(SlotCache &c, size_t bytes, size_t *actual) {
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (c.ptr && c.bytes >= bytes && c.bytes <= 2 * bytes + (1u << 20)) {
-        void *p = c.ptr;
-        *actual = c.bytes;
-        c.ptr = nullptr;
-        c.bytes = 0;
-        return p;
+void BufCache::drain() {
+    std::vector<Entry> gone;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        gone.swap(parked_);
+        total_ = 0;
     }
-    return nullptr;
+    for (const Entry &e : gone) raw_free(e.ptr);
 }
 
-/* returns the buffer that must be freed by the caller (the evicted one, or `ptr` itself when it is not worth parking) */
-void *slot_park(SlotCache &c, void *ptr, size_t bytes) {
-    if (!ptr) return nullptr;
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (bytes < (64u << 10)) return ptr;
-    void *evict = c.ptr;
-    c.ptr = ptr;
-    c.bytes = bytes;
-    return evict;
-}
+/* what a batch allocates: the int16 matrices, the arena of small arrays, the traceback line buffers (device + pinned) */
+BufCache g_matCache(BufCache::Device, 64, (size_t)96 << 30), g_arenaCache(BufCache::Device, 64, (size_t)2 << 30),
+    g_tbDevCache(BufCache::Device, 64, (size_t)8 << 30), g_tbHostCache(BufCache::PinnedHost, 64, (size_t)2 << 30);
 
 /* hipStreamCreate / hipStreamDestroy cost ~2 ms each on this stack: a finished batch parks its (idle) stream */
 struct StreamCache {
     std::mutex mu;
-    hipStream_t s = nullptr;
-    int device = -1;
-} g_stream;
+    std::vector<std::pair<hipStream_t, int>> parked; /* (stream, device) */
+} g_streams;
 
 hipError_t stream_take(hipStream_t *out) {
     {
-        std::lock_guard<std::mutex> lk(g_stream.mu);
-        if (g_stream.s && g_stream.device == g_device) { *out = g_stream.s; g_stream.s = nullptr; return hipSuccess; }
+        std::lock_guard<std::mutex> lk(g_streams.mu);
+        for (size_t i = 0; i < g_streams.parked.size(); i++)
+            if (g_streams.parked[i].second == g_device) {
+                *out = g_streams.parked[i].first;
+                g_streams.parked.erase(g_streams.parked.begin() + (long)i);
+                return hipSuccess;
+            }
     }
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
 void stream_park(hipStream_t s) {
     if (!s) return;
-    hipStream_t evict = nullptr;
     {
-        std::lock_guard<std::mutex> lk(g_stream.mu);
-        evict = g_stream.s;
-        g_stream.s = s;
-        g_stream.device = g_device;
+        std::lock_guard<std::mutex> lk(g_streams.mu);
+        if (g_streams.parked.size() < 64 && g_device >= 0) { g_streams.parked.emplace_back(s, g_device); return; }
     }
-    if (evict) (void)hipStreamDestroy(evict);
+    (void)hipStreamDestroy(s);
 }
 
-void pool_trim() {
-    {
-        hipStream_t st = nullptr;
-        { std::lock_guard<std::mutex> lk(g_stream.mu); st = g_stream.s; g_stream.s = nullptr; }
-        if (st) (void)hipStreamDestroy(st);
-    }
-    {
-        void *d = nullptr, *h = nullptr, *ar = nullptr;
-        { std::lock_guard<std::mutex> lk(g_arena.mu); ar = g_arena.ptr; g_arena.ptr = nullptr; g_arena.bytes = 0; }
-        if (ar) (void)hipFree(ar);
-        { std::lock_guard<std::mutex> lk(g_tbDev.mu); d = g_tbDev.ptr; g_tbDev.ptr = nullptr; g_tbDev.bytes = 0; }
-        { std::lock_guard<std::mutex> lk(g_tbHost.mu); h = g_tbHost.ptr; g_tbHost.ptr = nullptr; g_tbHost.bytes = 0; }
-        if (d) (void)hipFree(d);
-        if (h) (void)hipHostFree(h);
-    }
-    void *stale = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        stale = g_pool.ptr;
-        g_pool.ptr = nullptr;
-        g_pool.bytes = 0;
-    }
-    if (stale) (void)hipFree(stale);
+void trim_all_caches() {
+    std::vector<std::pair<hipStream_t, int>> st;
+    { std::lock_guard<std::mutex> lk(g_streams.mu); st.swap(g_streams.parked); }
+    for (auto &e : st) (void)hipStreamDestroy(e.first);
+    g_matCache.drain();
+    g_arenaCache.drain();
+    g_tbDevCache.drain();
+    g_tbHostCache.drain();
 }
 
 } // namespace
@@ -311,7 +308,7 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
 }
 
 int dpx_shutdown(void) {
-    pool_trim();
+    trim_all_caches();
     std::lock_guard<std::mutex> lk(g_mu);
     g_device = -1;
     return DPX_OK;
@@ -355,10 +352,10 @@ int dpx_batch_destroy(dpx_batch *b) {
     /* buffers are parked for the next batch, not freed: nothing of this batch may still be running on them */
     if (b->lastStream && b->lastStream != b->stream) (void)hipStreamSynchronize(b->lastStream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); stream_park(b->stream); }
-    if (void *ev = slot_park(g_arena, b->arena, b->arenaCap)) (void)hipFree(ev);
-    pool_release(b->dMat, b->matPoolBytes);
-    if (void *ev = slot_park(g_tbDev, b->dTb, b->dTbCap)) (void)hipFree(ev);
-    if (void *ev = slot_park(g_tbHost, b->hTb, b->hTbCap)) (void)hipHostFree(ev);
+    g_arenaCache.park(b->arena, b->arenaCap);
+    g_matCache.park(b->dMat, b->matPoolBytes);
+    g_tbDevCache.park(b->dTb, b->dTbCap);
+    g_tbHostCache.park(b->hTb, b->hTbCap);
     delete b;
     trace.mark("destroy");
     return DPX_OK;
@@ -491,8 +488,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
         const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
         const size_t need = szSeq + szPairs + 6 * szI32 + szOff; /* score, endRow, endCol, order, couples, tbLen */
-        if (void *rec = slot_take(g_arena, need, &b->arenaCap)) b->arena = (char *)rec;
-        else { CREATE_TRY(hipMalloc((void **)&b->arena, need)); b->arenaCap = need; }
+        CREATE_TRY(g_arenaCache.take((void **)&b->arena, need, &b->arenaCap));
         char *q = b->arena;
         b->dSeq = q;                  q += szSeq;
         b->dPairs = (dpx_pair_dev *)q; q += szPairs;
@@ -679,7 +675,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
     if (b->store && b->matElems) {
         void *pool = nullptr;
-        CREATE_TRY(pool_alloc(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
+        CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
         b->dMat = (int16_t *)pool;
     }
     trace.mark("create: H2D pairs+matrix pool");
@@ -838,13 +834,14 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     const dpx_pair_dev &pd = b->pairs[pair];
     const size_t total = (size_t)(pd.m + 1) * (size_t)(pd.n + 1);
     int16_t *dOut = nullptr;
+    size_t dOutCap = 0;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
-    HIP_TRY(hipMalloc((void **)&dOut, total * sizeof(int16_t)));
+    HIP_TRY(g_tbDevCache.take((void **)&dOut, total * sizeof(int16_t), &dOutCap)); /* row-major scratch */
     hipError_t e = dpx_launch_export(b->dMat, pd, b->kernelAlgo, b->R, b->planes, which, b->prm.gapOpen, b->prm.gapExtend,
                                      b->prm.band, dOut, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dOut, total * sizeof(int16_t), hipMemcpyDeviceToHost);
-    (void)hipFree(dOut);
+    g_tbDevCache.park(dOut, dOutCap);
     if (e != hipSuccess) return hip_fail(e, "dpx_batch_matrix");
     return DPX_OK;
 }
@@ -859,12 +856,10 @@ static int run_traceback(dpx_batch *b) {
         for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)(b->pairs[i].m + b->pairs[i].n + 1); }
         b->tbOff[np] = off;
         const size_t need = (size_t)std::max<uint64_t>(off, 16);
-        if (void *rec = slot_take(g_tbDev, need, &b->dTbCap)) b->dTb = (char *)rec;
-        else { HIP_TRY(hipMalloc((void **)&b->dTb, need)); b->dTbCap = need; }
+        HIP_TRY(g_tbDevCache.take((void **)&b->dTb, need, &b->dTbCap));
         HIP_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         b->hTbBytes = off;
-        if (void *rec = slot_take(g_tbHost, need, &b->hTbCap)) b->hTb = (char *)rec;
-        else { HIP_TRY(hipHostMalloc((void **)&b->hTb, need, hipHostMallocDefault)); b->hTbCap = need; }
+        HIP_TRY(g_tbHostCache.take((void **)&b->hTb, need, &b->hTbCap));
         b->hTbLen.resize(np);
     }
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
