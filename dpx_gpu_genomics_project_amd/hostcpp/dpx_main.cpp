@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,10 +25,12 @@
 
 namespace {
 
-struct BatchOut {
+struct BatchOut { // one text arena per batch instead of three std::strings per pair (300k small allocations per 100k pairs)
     size_t first = 0;
-    std::vector<int32_t> score;
-    std::vector<std::string> ref, rel, qry;
+    std::vector<int32_t> score, len;
+    std::vector<size_t> off; // lines of pair k: text[off[k] + l * (len[k] + 1)], l = 0 (reference), 1 (relation), 2 (query)
+    std::unique_ptr<char[]> text; // not a vector: no zero-fill of tens of MB that are overwritten anyway
+    size_t textCap = 0;
 };
 
 [[noreturn]] void die(const char *what, int rc) {
@@ -38,7 +41,11 @@ struct BatchOut {
 void print_batch(const BatchOut *o, bool local) {
     for (size_t k = 0; k < o->score.size(); k++) {
         if (local && o->score[k] == 0) printf("%zu | 0\n\n\n\n", o->first + k);
-        else printf("%zu | %d\n%s\n%s\n%s\n", o->first + k, o->score[k], o->ref[k].c_str(), o->rel[k].c_str(), o->qry[k].c_str());
+        else {
+            const char *t = o->text.get() + o->off[k];
+            const size_t stride = (size_t)o->len[k] + 1;
+            printf("%zu | %d\n%s\n%s\n%s\n", o->first + k, o->score[k], t, t + stride, t + 2 * stride);
+        }
     }
 }
 
@@ -111,7 +118,8 @@ int main(int argc, char *argv[]) {
     static_assert(sizeof(seqPair) == sizeof(dpx_seq_pair), "seqPair must stay layout-compatible with the C ABI");
 
     std::thread printer;
-    BatchOut *inFlight = nullptr;
+    BatchOut outs[2]; // batch k is printed from one while batch k+1 is assembled in the other; buffers are reused
+    size_t batchNo = 0;
     size_t shardCells = 0;
     for (size_t i = shardLo; i < shardHi; i++) shardCells += (size_t)sequenceIdxs[i].referenceSize * (size_t)sequenceIdxs[i].querySize;
     for (size_t first = shardLo; first < shardHi; first += batchSize) {
@@ -128,21 +136,28 @@ int main(int argc, char *argv[]) {
         kernel_time += (uint64_t)usec;
 
         t0 = get_time();
-        BatchOut *out = new BatchOut();
+        BatchOut *out = &outs[batchNo++ & 1];
         out->first = first;
         out->score.resize(count);
         if ((rc = dpx_batch_results(b, out->score.data(), nullptr, nullptr)) != DPX_OK) die("FAILED TO COPY SCORES", rc);
         if (print) {
-            out->ref.resize(count); out->rel.resize(count); out->qry.resize(count);
-            std::vector<char> l0, l1, l2;
+            out->len.resize(count);
+            out->off.resize(count);
+            size_t total = 0; // worst case: an alignment is at most m + n columns long
+            for (size_t k = 0; k < count; k++)
+                total += 3 * ((size_t)sequenceIdxs[first + k].referenceSize + (size_t)sequenceIdxs[first + k].querySize + 2);
+            if (out->textCap < total) { out->text.reset(new char[total]); out->textCap = total; }
+            size_t at = 0;
             for (size_t k = 0; k < count; k++) {
                 const size_t cap = (size_t)sequenceIdxs[first + k].referenceSize + (size_t)sequenceIdxs[first + k].querySize + 2;
-                if (l0.size() < cap) { l0.resize(cap); l1.resize(cap); l2.resize(cap); }
+                char *t = out->text.get() + at; // the three lines land back to back once the length is known
                 int32_t len = 0;
-                if ((rc = dpx_batch_traceback(b, k, l0.data(), l1.data(), l2.data(), &len)) != DPX_OK) die("TRACEBACK FAILED", rc);
-                out->ref[k].assign(l0.data(), (size_t)len);
-                out->rel[k].assign(l1.data(), (size_t)len);
-                out->qry[k].assign(l2.data(), (size_t)len);
+                if ((rc = dpx_batch_traceback(b, k, t, t + cap, t + 2 * cap, &len)) != DPX_OK) die("TRACEBACK FAILED", rc);
+                const size_t stride = (size_t)len + 1;
+                if (stride != cap) { memmove(t + stride, t + cap, stride); memmove(t + 2 * stride, t + 2 * cap, stride); }
+                out->off[k] = at;
+                out->len[k] = len;
+                at += 3 * stride;
             }
         }
         backtracking_time += get_time() - t0;
@@ -151,12 +166,10 @@ int main(int argc, char *argv[]) {
         memalloc_time += get_time() - t0;
 
         // hand the finished batch to the printer; it prints while the next batch is created and filled
-        if (printer.joinable()) { t0 = get_time(); printer.join(); printing_time += get_time() - t0; delete inFlight; }
-        inFlight = out;
+        if (printer.joinable()) { t0 = get_time(); printer.join(); printing_time += get_time() - t0; }
         if (print) printer = std::thread(print_batch, out, local);
     }
     if (printer.joinable()) { uint64_t t0 = get_time(); printer.join(); printing_time += get_time() - t0; }
-    delete inFlight;
 
     const uint64_t elapsed_time = get_elapsed_time();
     printf("Elapsed time (usec): %llu\n", (unsigned long long)elapsed_time);
