@@ -1,10 +1,10 @@
-// dpx_cpu_main.cpp -- the reference's c++/main.cpp shape on the MI355X engine: batches of THREADS_PER_BATCH pthreads,
+// dpx_class_main.cpp -- the reference's c++/main.cpp shape on the MI355X engine: batches of THREADS_PER_BATCH pthreads,
 // each aligning PAIRS_PER_THREAD consecutive pairs through the SequenceAligner-derived classes (c++/main.cpp:18-19,
 // 166-232), same argv, same stdout lines.  Differences, all fixes of upstream defects that never change a printed
 // block: the algorithm is a run-time flag instead of a #define (main.cpp:22-24), pairs past the last full 400 are
 // not dropped (main.cpp:169 floors twice) and the per-thread loop is clamped to numPairs (main.cpp:61 is not).
 //
-//   dpx_cpu_main -pairs <file> -match M -mismatch X -open O [-extend E] [-algo LSW|LNW|ANW|BSW] [-band B]
+//   dpx_class_main -pairs <file> -match M -mismatch X -open O [-extend E] [-algo LSW|LNW|ANW|BSW] [-band B]
 #include <pthread.h>
 
 #include <cassert>
@@ -51,7 +51,7 @@ void *threadCompute(void *tmp) {
 
 int main(int argc, char *argv[]) {
     if (argc < 3) {
-        fprintf(stderr, "usage: dpx_cpu_main -pairs <InSeqFile> -match <matchWeight> -mismatch <mismatchWeight> -open <gapWeight> "
+        fprintf(stderr, "usage: dpx_class_main -pairs <InSeqFile> -match <matchWeight> -mismatch <mismatchWeight> -open <gapWeight> "
                         "[-extend <gapExtend>] [-algo LSW|LNW|ANW|BSW] [-band <B>]\n");
         exit(EXIT_FAILURE);
     }

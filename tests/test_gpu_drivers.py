@@ -4,7 +4,7 @@
   headers and libdpxalign.so (hostcpp/Makefile `dropin`; built in the container that has /root/reference, the binary
   travels to the GPU box) -- must print, after reordering by pair number (its 20 pthreads print in any order, which
   is what scripts/reorderOutput.py exists for), exactly the blocks the reference's CPU classes print.
-* dpx_cpu_main (same shape, run-time algorithm flag, tail fixed) and dpx_main (batched, pipelined GPU driver).
+* dpx_class_main (same shape, run-time algorithm flag, tail fixed) and dpx_main (batched, pipelined GPU driver).
 """
 import gzip
 import os
@@ -66,7 +66,7 @@ def test_reference_main_cpp_drops_onto_the_engine(algo):
 def test_class_driver_and_batched_driver_match_reference_stdout(algo):
     subprocess.run(["make", "-s", "-C", HOST], check=True)
     pairs = os.path.join(G, "short400.txt")
-    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_cpu_main"), "-pairs", pairs] + W[algo] + ["-algo", algo]))
+    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_class_main"), "-pairs", pairs] + W[algo] + ["-algo", algo]))
     assert "".join(blocks[p] for p in range(400)) == golden(algo)
     # batched driver prints in input order; 3 uneven batches exercise the printer pipeline
     out = run([os.path.join(HOST, "dpx_main"), "-pairs", pairs] + W[algo] + ["-algo", algo, "-batch", "150"])
@@ -87,7 +87,7 @@ def test_tail_pairs_are_not_dropped(tmp_path):
         o = O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2)
         a, b, c = ("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)
         want += f"{p} | {o.score}\n{a}\n{b}\n{c}\n"
-    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_cpu_main"), "-pairs", path] + W["LSW"]))
+    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_class_main"), "-pairs", path] + W["LSW"]))
     assert "".join(blocks[p] for p in range(37)) == want
     out = run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W["LSW"] + ["-algo", "BSW", "-band", "1000"])
     assert out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time")] == want

@@ -5,7 +5,7 @@
 
 Header lines (before the first "<n> | <score>" block) and footer lines ("Elapsed time", "Cleaning up", statistics)
 keep their places; result blocks ("<n> | <score>" + three lines, which may be empty) are emitted in pair order.
-dpx_main prints in order already; this is for dpx_cpu_main / the reference's main.cpp, whose 20 pthreads race for stdout.
+dpx_main prints in order already; this is for dpx_class_main / the reference's main.cpp, whose 20 pthreads race for stdout.
 """
 import re
 import sys
