@@ -39,6 +39,8 @@ WORKLOADS = {
     "lnw_10k_1024": ("LNW", 10000, 1024, 1024, 3, -1, -2, -1, 7),
     "bsw_10k_4096_b128": ("BSW", 10000, 4096, 4096, 3, -1, -2, -1, 4),  # band 128 (BASELINE.json configs[3])
     # the reference's own dataset shape (configs[0]: short reads, reference 100-160, query 80-130); m = n = 0 -> ragged
+    # BASELINE.json configs[4]: 100k pairs in total, sharded over the ranks (strong scaling; 12.5k pairs = 27.8 GB per GPU at N = 8)
+    "lsw_100k_1024_sharded": ("LSW", -100000, 1024, 1024, 3, -1, -2, -1, 5),
     "lnw_100k_short": ("LNW", 100000, 0, 0, 3, -1, -2, -1, 6),
     "lsw_100k_short": ("LSW", 100000, 0, 0, 3, -1, -2, -1, 6),
     "anw_100k_short": ("ANW", 100000, 0, 0, 3, -1, -3, -1, 6),
@@ -140,6 +142,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     algo_name, npairs, m, n, match, mismatch, gap_open, gap_extend, seed = WORKLOADS[args.workload]
+    strong = npairs < 0  # negative = total over all ranks: each rank takes its contiguous ceil(N/G)-sized shard
+    if strong:
+        from dpx_gpu_genomics_project_amd.shard import shard_range
+        lo, hi = shard_range(-npairs, rank, world)
+        if (hi - lo) * world != -npairs:
+            sys.exit(f"{args.workload}: {-npairs} pairs do not split evenly over {world} ranks")
+        npairs = hi - lo
     if args.pairs:
         npairs = args.pairs
     algo = {"LNW": dpx.ALGO_LNW, "LSW": dpx.ALGO_LSW, "ANW": dpx.ALGO_ANW, "BSW": dpx.ALGO_BSW}[algo_name]
@@ -227,7 +236,7 @@ def main():
         out = {
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{algo_name} {npairs}-pair {shape} batch per GPU, int16 score matrix written to HBM",
                        "algorithm": algo_name, "pairs_per_gpu": npairs, "query_len": m, "reference_len": n,
                        "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
