@@ -103,8 +103,8 @@ def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pa
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="lsw_10k_1024", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,6 +185,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device preconditioning (setup, untimed, not a step): after idle the chip needs ~80 ms of load before it holds its
+    # steady clock -- the first ~20 fills of a process run ~4 % slower (tools/cold_start.py, profiles/README.md).  A fixed
+    # 0.25 s of fills here makes the timed region measure sustained throughput whatever --warmup says.
+    t_pre = time.perf_counter()
+    precondition_fills = 0
+    while time.perf_counter() - t_pre < 0.25:
+        batch.fill(stream)
+        torch.cuda.synchronize()
+        precondition_fills += 1
     for _ in range(args.warmup):
         step()
     fence()
@@ -241,7 +250,8 @@ def main():
                        "algorithm": algo_name, "pairs_per_gpu": npairs, "query_len": m, "reference_len": n,
                        "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
                        "parallelism": f"{world} rank(s), 1 per GPU, pairs sharded, RCCL gather of int32 scores" if world > 1 else "1 GPU",
-                       "cells_per_gpu": info["cells"], "matrix_bytes_per_gpu": info["matrix_bytes"]},
+                       "cells_per_gpu": info["cells"], "matrix_bytes_per_gpu": info["matrix_bytes"],
+                       "precondition_fills": precondition_fills},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],

@@ -29,9 +29,10 @@ def per_launch(counter):
             continue
         acc.setdefault(r["Dispatch_Id"], [k, 0.0])[1] += float(r["Counter_Value"])
     names = sorted({v[0] for v in acc.values()})
-    # a batch may need more than one fill kernel per step (couples + leftovers, 8-row + 16-row quad classes): sum per step
-    steps = 4  # --steps 3 --warmup 1
-    return sum(v[1] for v in acc.values()) / steps, names
+    # a batch may need more than one fill kernel per fill (couples + leftovers, 8-row + 16-row quad classes), each launched
+    # once per fill: fills = dispatches of any one of them (bench.py also runs untimed preconditioning fills)
+    fills = max(sum(1 for v in acc.values() if v[0] == nm) for nm in names)
+    return sum(v[1] for v in acc.values()) / fills, names
 w, names = per_launch("WRITE_SIZE")
 f, _ = per_launch("FETCH_SIZE")
 res = {"workload": wl, "fill_kernels": names, "WRITE_SIZE_KB_per_fill": w, "FETCH_SIZE_KB_per_fill": f,
