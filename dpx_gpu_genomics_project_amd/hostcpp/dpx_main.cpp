@@ -103,13 +103,14 @@ int main(int argc, char *argv[]) {
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;
     char *sequences;
-    inputInfo fileInfo = parseInput(pairFileName, sequenceIdxs, sequences);
-    printf("Num Pairs: %zu\n\n", fileInfo.numPairs);
-    /* this rank's shard: contiguous ceil(N/world)-sized ranges */
-    const size_t perRank = (fileInfo.numPairs + (size_t)world - 1) / (size_t)world;
-    const size_t shardLo = std::min(fileInfo.numPairs, perRank * (size_t)rank);
-    const size_t shardHi = std::min(fileInfo.numPairs, shardLo + perRank);
-    if (world > 1) printf("Rank %d of %d: pairs [%zu, %zu)\n\n", rank, world, shardLo, shardHi);
+    // one process per GPU: every rank maps the file and materialises only its own contiguous ceil(N/world)-sized shard
+    size_t shardFirst = 0, totalPairs = 0;
+    inputInfo fileInfo = world > 1 ? parseInputShard(pairFileName, rank, world, sequenceIdxs, sequences, shardFirst, totalPairs)
+                                   : parseInput(pairFileName, sequenceIdxs, sequences);
+    if (world == 1) totalPairs = fileInfo.numPairs;
+    printf("Num Pairs: %zu\n\n", totalPairs);
+    const size_t shardLo = 0, shardHi = fileInfo.numPairs; // indices into this rank's own records
+    if (world > 1) printf("Rank %d of %d: pairs [%zu, %zu)\n\n", rank, world, shardFirst, shardFirst + fileInfo.numPairs);
 
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
@@ -137,7 +138,7 @@ int main(int argc, char *argv[]) {
 
         t0 = get_time();
         BatchOut *out = &outs[batchNo++ & 1];
-        out->first = first;
+        out->first = shardFirst + first; // global pair number of the batch's first pair
         out->score.resize(count);
         if ((rc = dpx_batch_results(b, out->score.data(), nullptr, nullptr)) != DPX_OK) die("FAILED TO COPY SCORES", rc);
         if (print) {
@@ -173,7 +174,7 @@ int main(int argc, char *argv[]) {
 
     const uint64_t elapsed_time = get_elapsed_time();
     printf("Elapsed time (usec): %llu\n", (unsigned long long)elapsed_time);
-    printf("Num Pairs: %zu\n", fileInfo.numPairs);
+    printf("Num Pairs: %zu\n", totalPairs);
     printf("Num Cells: %zu\n", fileInfo.numCells);
     printf("Reference length min/avg/max: %zu / %.1f / %zu\n", fileInfo.minReferenceLength, fileInfo.avgReferenceLength, fileInfo.maxReferenceLength);
     printf("Query length min/avg/max: %zu / %.1f / %zu\n", fileInfo.minQueryLength, fileInfo.avgQueryLength, fileInfo.maxQueryLength);

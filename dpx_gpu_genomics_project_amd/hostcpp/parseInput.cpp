@@ -4,6 +4,12 @@
 #include "parseInput.h"
 
 #include <cstring>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 const size_t kInputCap = 10000000; // reference: #define INPUT_CAP (parseInput.cpp:7)
@@ -14,31 +20,9 @@ const size_t kInputCap = 10000000; // reference: #define INPUT_CAP (parseInput.c
 }
 } // namespace
 
-inputInfo parseInput(const char *pairFileName, seqPair *&sequenceIdxs, char *&sequences) {
-    FILE *f = fopen(pairFileName, "rb");
-    if (!f) die("Could not open file: %s\n", pairFileName);
-    if (fseek(f, 0, SEEK_END) != 0) die("Could not size file: %s\n", pairFileName);
-    const long fileSize = ftell(f);
-    if (fileSize < 0) die("Could not size file: %s\n", pairFileName);
-    rewind(f);
-    const size_t numBytes = (size_t)fileSize;
-    sequences = (char *)malloc(numBytes ? numBytes : 1);
-    if (!sequences) die("Out of memory reading: %s\n", pairFileName);
-    size_t got = 0;
-    while (got < numBytes) {
-        const size_t k = fread(sequences + got, 1, numBytes - got, f);
-        if (k == 0) die("Did not read all bytes of: %s\n", pairFileName);
-        got += k;
-    }
-    fclose(f);
-
-    size_t numLines = 0;
-    for (const char *p = sequences, *e = sequences + numBytes; (p = (const char *)memchr(p, '\n', (size_t)(e - p))) != nullptr; ++p) numLines++;
-    if (numLines % 3 != 0) die("Number of lines not a multiple of 3: %s\n", pairFileName);
-    size_t numPairs = numLines / 3;
-    sequenceIdxs = (seqPair *)malloc((numPairs ? numPairs : 1) * sizeof(seqPair));
-    if (!sequenceIdxs) die("Out of memory indexing: %s\n", pairFileName);
-
+namespace {
+// walk `numBytes` of '\n'-terminated lines (3 per pair): terminate them with '\0', record offsets / lengths, gather statistics
+inputInfo indexLines(char *sequences, size_t numBytes, size_t numPairs, seqPair *sequenceIdxs) {
     inputInfo info;
     info.numPairs = numPairs;
     info.numBytes = numBytes;
@@ -82,6 +66,74 @@ inputInfo parseInput(const char *pairFileName, seqPair *&sequenceIdxs, char *&se
     info.avgReferenceLength = info.numPairs ? sumRef / (double)info.numPairs : 0.0;
     info.avgQueryLength = info.numPairs ? sumQry / (double)info.numPairs : 0.0;
     return info;
+}
+} // namespace
+
+inputInfo parseInput(const char *pairFileName, seqPair *&sequenceIdxs, char *&sequences) {
+    FILE *f = fopen(pairFileName, "rb");
+    if (!f) die("Could not open file: %s\n", pairFileName);
+    if (fseek(f, 0, SEEK_END) != 0) die("Could not size file: %s\n", pairFileName);
+    const long fileSize = ftell(f);
+    if (fileSize < 0) die("Could not size file: %s\n", pairFileName);
+    rewind(f);
+    const size_t numBytes = (size_t)fileSize;
+    sequences = (char *)malloc(numBytes ? numBytes : 1);
+    if (!sequences) die("Out of memory reading: %s\n", pairFileName);
+    size_t got = 0;
+    while (got < numBytes) {
+        const size_t k = fread(sequences + got, 1, numBytes - got, f);
+        if (k == 0) die("Did not read all bytes of: %s\n", pairFileName);
+        got += k;
+    }
+    fclose(f);
+
+    size_t numLines = 0;
+    for (const char *p = sequences, *e = sequences + numBytes; (p = (const char *)memchr(p, '\n', (size_t)(e - p))) != nullptr; ++p) numLines++;
+    if (numLines % 3 != 0) die("Number of lines not a multiple of 3: %s\n", pairFileName);
+    size_t numPairs = numLines / 3;
+    sequenceIdxs = (seqPair *)malloc((numPairs ? numPairs : 1) * sizeof(seqPair));
+    if (!sequenceIdxs) die("Out of memory indexing: %s\n", pairFileName);
+
+    return indexLines(sequences, numBytes, numPairs, sequenceIdxs);
+}
+
+inputInfo parseInputShard(const char *pairFileName, int rank, int world, seqPair *&sequenceIdxs, char *&sequences,
+                          size_t &firstPair, size_t &totalPairs) {
+    if (world < 1 || rank < 0 || rank >= world) die("Bad shard request for: %s\n", pairFileName);
+    const int fd = open(pairFileName, O_RDONLY);
+    if (fd < 0) die("Could not open file: %s\n", pairFileName);
+    struct stat st;
+    if (fstat(fd, &st) != 0) die("Could not size file: %s\n", pairFileName);
+    const size_t fileBytes = (size_t)st.st_size;
+    const char *map = fileBytes ? (const char *)mmap(nullptr, fileBytes, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    if (fileBytes && map == MAP_FAILED) die("Could not map file: %s\n", pairFileName);
+    close(fd);
+
+    // one pass over the newlines: where does every pair (every third line) start?
+    std::vector<size_t> pairStart;
+    size_t numLines = 0, lineStart = 0;
+    while (lineStart < fileBytes) {
+        const char *nl = (const char *)memchr(map + lineStart, '\n', fileBytes - lineStart);
+        if (!nl) break; // bytes after the last newline belong to no line (parseInput does not index them either)
+        if (numLines % 3 == 0) pairStart.push_back(lineStart);
+        numLines++;
+        lineStart = (size_t)(nl - map) + 1;
+    }
+    if (numLines % 3 != 0) die("Number of lines not a multiple of 3: %s\n", pairFileName);
+    pairStart.push_back(lineStart); // sentinel: one past the last pair's query line
+    totalPairs = std::min(numLines / 3, kInputCap);
+
+    const size_t perRank = (totalPairs + (size_t)world - 1) / (size_t)world;
+    firstPair = std::min(totalPairs, perRank * (size_t)rank);
+    const size_t lastPair = std::min(totalPairs, firstPair + perRank);
+    const size_t lo = pairStart[firstPair], hi = pairStart[lastPair];
+    const size_t numBytes = hi - lo, numPairs = lastPair - firstPair;
+    sequences = (char *)malloc(numBytes ? numBytes : 1);
+    sequenceIdxs = (seqPair *)malloc((numPairs ? numPairs : 1) * sizeof(seqPair));
+    if (!sequences || !sequenceIdxs) die("Out of memory reading: %s\n", pairFileName);
+    if (numBytes) memcpy(sequences, map + lo, numBytes);
+    if (map) munmap((void *)map, fileBytes);
+    return indexLines(sequences, numBytes, numPairs, sequenceIdxs);
 }
 
 void printParsedFile(const size_t numPairs, const seqPair *idx, const char *sequences) {

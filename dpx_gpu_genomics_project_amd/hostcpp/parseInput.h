@@ -31,5 +31,13 @@ struct seqPair {
 };
 
 inputInfo parseInput(const char *pairFileName, seqPair *&sequence_indices, char *&sequences);
+
+// Shard loader for one-process-per-GPU runs (not in the reference).  Maps the file, walks its newlines once
+// and materialises ONLY pairs [firstPair, firstPair + info.numPairs) = the rank's contiguous ceil(N/world)-sized range:
+// `sequences` holds just those lines ('\n' -> '\0'), the seqPair offsets are relative to it, the statistics in the
+// returned inputInfo describe the shard, `totalPairs` is the pair count of the whole file.  Same failure modes as
+// parseInput (message on stderr + exit(1)); world == 1 yields parseInput's records.
+inputInfo parseInputShard(const char *pairFileName, int rank, int world, seqPair *&sequence_indices, char *&sequences,
+                          size_t &firstPair, size_t &totalPairs);
 void printParsedFile(const size_t numPairs, const seqPair *sequence_indices, const char *sequences);
 void cleanupParsedFile(seqPair *sequence_indices, char *sequences);

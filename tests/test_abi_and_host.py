@@ -88,3 +88,44 @@ def test_reorder_output_tool():
     text = "Parsing input file: x\nPair # | Score\n2 | 0\n\n\n\n0 | 5\nAC\n**\nAC\n1 | -3\nA_\n* \nAG\nElapsed time (usec): 7\nCleaning up\n"
     want = "Parsing input file: x\nPair # | Score\n0 | 5\nAC\n**\nAC\n1 | -3\nA_\n* \nAG\n2 | 0\n\n\n\nElapsed time (usec): 7\nCleaning up\n"
     assert mod.reorder(text) == want
+
+
+def _fnv(sb, lo, hi):
+    h = 1469598103934665603
+    for p in range(lo, hi):
+        for part in (sb.ref(p), sb.qry(p)):
+            for c in part:
+                h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return format(h, "x")
+
+
+def test_cpp_loaders_agree_with_the_file_format(tmp_path):
+    """hostcpp/parseInput.cpp (the reference's loader, mirrored) and parseInputShard (mmap, one pass, only the rank's
+    pairs) against the Python restatement of the format, for the whole file and for every rank of 1-, 3- and 8-way splits."""
+    import json
+    import subprocess
+    host = os.path.join(ROOT, "dpx_gpu_genomics_project_amd", "hostcpp")
+    subprocess.run(["make", "-s", "-C", host, "parse_tool"], check=True)
+    tool = os.path.join(host, "parse_tool")
+    sb = make_ragged_batch(101, 1, 60, 1, 70, seed=8)
+    path = str(tmp_path / "pairs.txt")
+    write_pairs_file(sb, path)
+    whole = json.loads(subprocess.run([tool, path], capture_output=True, text=True, check=True).stdout)
+    sizes = [[int(r["referenceSize"]), int(r["querySize"])] for r in sb.pairs]
+    assert whole["numPairs"] == whole["totalPairs"] == 101 and whole["sizes"] == sizes
+    assert whole["numBytes"] == os.path.getsize(path) and whole["fnv"] == _fnv(sb, 0, 101)
+    assert whole["numCells"] == sum(a * b for a, b in sizes)
+    for world in (1, 3, 8):
+        seen = 0
+        for rank in range(world):
+            part = json.loads(subprocess.run([tool, path, str(rank), str(world)], capture_output=True, text=True, check=True).stdout)
+            lo, hi = shard_range(101, rank, world)
+            assert (part["firstPair"], part["numPairs"], part["totalPairs"]) == (lo, hi - lo, 101)
+            assert part["sizes"] == sizes[lo:hi] and part["fnv"] == _fnv(sb, lo, hi)
+            assert part["numCells"] == sum(a * b for a, b in sizes[lo:hi])
+            seen += part["numBytes"]
+        assert seen == os.path.getsize(path)          # the shards partition the file's bytes
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "wb").write(b"0\nACGT\n")
+    r = subprocess.run([tool, bad, "0", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "multiple of 3" in r.stderr      # same failure mode as parseInput.cpp:38-41
