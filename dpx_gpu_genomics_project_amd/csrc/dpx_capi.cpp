@@ -345,6 +345,17 @@ static bool fits_int16(const dpx_params &p, long long m, long long n) {
     return lo >= -lim && hi <= lim;
 }
 
+/* cells (i, j) with 1 <= i <= m, 1 <= j <= n, |i - j| <= B - 1: sum over the rows of min(n, i+B-1) - max(1, i-B+1) + 1 */
+static uint64_t band_cells(long long m, long long n, long long B) {
+    if (m <= 0 || n <= 0 || B <= 0) return 0;
+    const long long M = std::min(m, n + B - 1);                 /* rows that still reach the band */
+    const long long a = std::max(0ll, std::min(n - B + 1, M));  /* rows whose right end is i + B - 1 (not clipped at n) */
+    const long long s1 = a * (a + 1) / 2 + a * (B - 1) + (M - a) * n;
+    const long long b = std::min(B, M);                         /* rows whose left end is clipped at column 1 */
+    const long long s2 = b + (M > B ? (M - B + 1) * (M - B + 2) / 2 - 1 : 0);
+    return (uint64_t)(s1 - s2 + M);
+}
+
 int dpx_batch_destroy(dpx_batch *b) {
     if (!b) return DPX_OK;
     PhaseTrace trace;
@@ -434,11 +445,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->algBytes += (uint64_t)pd.m + (uint64_t)pd.n + 16u + 12u;
         if (b->store) {
             if (banded) { /* 2 B per in-band cell */
-                uint64_t inband = 0;
-                for (int i = 1; i <= pd.m; i++) {
-                    const int lo = std::max(1, i - params->band + 1), hi = std::min(pd.n, i + params->band - 1);
-                    if (hi >= lo) inband += (uint64_t)(hi - lo + 1);
-                }
+                const uint64_t inband = band_cells(pd.m, pd.n, params->band);
                 b->bandCells += inband;
                 b->algBytes += 2ull * inband;
             } else {

@@ -69,3 +69,18 @@ def test_band_over_512_is_refused_not_faked(gpu):
     with pytest.raises(gpu.DpxError) as e:
         gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=600)
     assert e.value.status == -8
+
+
+def test_algorithmic_bytes_count_the_in_band_cells(gpu):
+    """a banded batch is priced at 2 B per in-band cell (+ sequences, 16 B pair record, 12 B result)."""
+    sb = make_ragged_batch(30, 1, 90, 1, 90, seed=12)
+    for band in (1, 7, 64, 200):
+        want = 0
+        for r in sb.pairs:
+            m, n = int(r["querySize"]), int(r["referenceSize"])
+            cells = sum(max(0, min(n, i + band - 1) - max(1, i - band + 1) + 1) for i in range(1, m + 1))
+            want += 2 * cells + m + n + 28
+        if band >= 90:   # the band covers every matrix: the batch runs (and is priced) as unbanded LSW
+            want = sum(2 * (int(r["querySize"]) + 1) * (int(r["referenceSize"]) + 1) + int(r["querySize"]) + int(r["referenceSize"]) + 28 for r in sb.pairs)
+        with gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=band) as b:
+            assert b.info()["algorithmic_bytes"] == want, band
