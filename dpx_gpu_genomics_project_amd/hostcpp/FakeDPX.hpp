@@ -6,47 +6,49 @@
 // kernels use the device functions directly.)
 #pragma once
 
+using dpx_u32 = unsigned int; // two int16 / uint16 halves for the *16x2 forms (pair A high, pair B low)
+
 class FakeDPX {
   public:
-    static int __vimax3_s32(const int a, const int b, const int c);
-    static unsigned int __vimax3_s16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __vimax3_u32(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __vimax3_u16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static int __vimin3_s32(const int a, const int b, const int c);
-    static unsigned int __vimin3_s16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __vimin3_u32(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __vimin3_u16x2(const unsigned int a, const unsigned int b, const unsigned int c);
+    static int __vimax3_s32(int x, int y, int z);
+    static dpx_u32 __vimax3_s16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __vimax3_u32(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __vimax3_u16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static int __vimin3_s32(int x, int y, int z);
+    static dpx_u32 __vimin3_s16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __vimin3_u32(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __vimin3_u16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
 
-    static int __vimax_s32_relu(const int a, const int b);
-    static unsigned int __vimax_s16x2_relu(const unsigned int a, const unsigned int b);
-    static int __vimin_s32_relu(const int a, const int b);
-    static unsigned int __vimin_s16x2_relu(const unsigned int a, const unsigned int b);
+    static int __vimax_s32_relu(int x, int y);
+    static dpx_u32 __vimax_s16x2_relu(dpx_u32 x, dpx_u32 y);
+    static int __vimin_s32_relu(int x, int y);
+    static dpx_u32 __vimin_s16x2_relu(dpx_u32 x, dpx_u32 y);
 
-    static int __vimax3_s32_relu(const int a, const int b, const int c);
-    static unsigned int __vimax3_s16x2_relu(const unsigned int a, const unsigned int b, const unsigned int c);
-    static int __vimin3_s32_relu(const int a, const int b, const int c);
-    static unsigned int __vimin3_s16x2_relu(const unsigned int a, const unsigned int b, const unsigned int c);
+    static int __vimax3_s32_relu(int x, int y, int z);
+    static dpx_u32 __vimax3_s16x2_relu(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static int __vimin3_s32_relu(int x, int y, int z);
+    static dpx_u32 __vimin3_s16x2_relu(dpx_u32 x, dpx_u32 y, dpx_u32 z);
 
-    static int __vibmax_s32(const int a, const int b, bool *const pred);
-    static unsigned int __vibmax_u32(const unsigned int a, const unsigned int b, bool *const pred);
-    static int __vibmin_s32(const int a, const int b, bool *const pred);
-    static unsigned int __vibmin_u32(const unsigned int a, const unsigned int b, bool *const pred);
-    static unsigned int __vibmax_s16x2(const unsigned int a, const unsigned int b, bool *const pred_hi, bool *const pred_lo);
-    static unsigned int __vibmax_u16x2(const unsigned int a, const unsigned int b, bool *const pred_hi, bool *const pred_lo);
-    static unsigned int __vibmin_s16x2(const unsigned int a, const unsigned int b, bool *const pred_hi, bool *const pred_lo);
-    static unsigned int __vibmin_u16x2(const unsigned int a, const unsigned int b, bool *const pred_hi, bool *const pred_lo);
+    static int __vibmax_s32(int x, int y, bool *firstWins);
+    static dpx_u32 __vibmax_u32(dpx_u32 x, dpx_u32 y, bool *firstWins);
+    static int __vibmin_s32(int x, int y, bool *firstWins);
+    static dpx_u32 __vibmin_u32(dpx_u32 x, dpx_u32 y, bool *firstWins);
+    static dpx_u32 __vibmax_s16x2(dpx_u32 x, dpx_u32 y, bool *hiWins, bool *loWins);
+    static dpx_u32 __vibmax_u16x2(dpx_u32 x, dpx_u32 y, bool *hiWins, bool *loWins);
+    static dpx_u32 __vibmin_s16x2(dpx_u32 x, dpx_u32 y, bool *hiWins, bool *loWins);
+    static dpx_u32 __vibmin_u16x2(dpx_u32 x, dpx_u32 y, bool *hiWins, bool *loWins);
 
-    static int __viaddmax_s32(const int a, const int b, const int c);
-    static unsigned int __viaddmax_u32(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __viaddmax_s16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __viaddmax_u16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static int __viaddmin_s32(const int a, const int b, const int c);
-    static unsigned int __viaddmin_u32(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __viaddmin_s16x2(const unsigned int a, const unsigned int b, const unsigned int c);
-    static unsigned int __viaddmin_u16x2(const unsigned int a, const unsigned int b, const unsigned int c);
+    static int __viaddmax_s32(int x, int y, int z);
+    static dpx_u32 __viaddmax_u32(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __viaddmax_s16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __viaddmax_u16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static int __viaddmin_s32(int x, int y, int z);
+    static dpx_u32 __viaddmin_u32(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __viaddmin_s16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static dpx_u32 __viaddmin_u16x2(dpx_u32 x, dpx_u32 y, dpx_u32 z);
 
-    static int __viaddmax_s32_relu(const int a, const int b, const int c);
-    static unsigned int __viaddmax_s16x2_relu(const unsigned int a, const unsigned int b, const unsigned int c);
-    static int __viaddmin_s32_relu(const int a, const int b, const int c);
-    static unsigned int __viaddmin_s16x2_relu(const unsigned int a, const unsigned int b, const unsigned int c);
+    static int __viaddmax_s32_relu(int x, int y, int z);
+    static dpx_u32 __viaddmax_s16x2_relu(dpx_u32 x, dpx_u32 y, dpx_u32 z);
+    static int __viaddmin_s32_relu(int x, int y, int z);
+    static dpx_u32 __viaddmin_s16x2_relu(dpx_u32 x, dpx_u32 y, dpx_u32 z);
 };

@@ -11,23 +11,18 @@
 
 #define PRINT_PARSED_PAIRS
 
-struct inputInfo {
-    size_t numPairs;
-    size_t numBytes;
-    size_t numCells; // sum of referenceSize * querySize: the denominator of GCUPS
-    size_t minReferenceLength;
-    size_t minQueryLength;
-    size_t maxReferenceLength;
-    size_t maxQueryLength;
-    double avgReferenceLength;
-    double avgQueryLength;
+struct seqPair { // one alignment pair: where its two strings start in the flat buffer and how long they are
+    int referenceIdx, referenceSize;
+    int queryIdx, querySize;
 };
+static_assert(sizeof(seqPair) == 16, "seqPair is also the C ABI's dpx_seq_pair");
 
-struct seqPair {
-    int referenceIdx;
-    int referenceSize;
-    int queryIdx;
-    int querySize;
+struct inputInfo { // what the loader saw
+    size_t numPairs, numBytes;
+    size_t numCells;                                  // sum of referenceSize * querySize: the denominator of GCUPS
+    size_t minReferenceLength, minQueryLength;
+    size_t maxReferenceLength, maxQueryLength;
+    double avgReferenceLength, avgQueryLength;
 };
 
 inputInfo parseInput(const char *pairFileName, seqPair *&sequence_indices, char *&sequences);

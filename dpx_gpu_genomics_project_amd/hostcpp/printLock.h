@@ -1,9 +1,21 @@
-// printLock.h -- one process-wide stdout mutex (reference: c++/printLock.h:1-8, printLock.cpp:3-10).
-// USE_THREADS is defined here exactly as the reference does, because its main.cpp keys its pthread driver on it.
-#pragma once
-#include "pthread.h"
+// printLock.h -- one process-wide stdout mutex, the interface of the reference's c++/printLock.h:1-8 (bodies:
+// printLock.cpp).  The reference's main.cpp keys its pthread driver on USE_THREADS being defined by this header.
+#ifndef DPX_HOSTCPP_PRINTLOCK_H
+#define DPX_HOSTCPP_PRINTLOCK_H
+#include <pthread.h>
 
-#define USE_THREADS
+#ifndef USE_THREADS
+#define USE_THREADS 1
+#endif
 
-void printLock();
-void printUnlock();
+void printLock();   // blocks until this thread owns stdout
+void printUnlock(); // releases it (call after fflush(stdout))
+
+// scope guard for new code: { PrintGuard g; printf(...); } -- flushes before it lets go
+struct PrintGuard {
+    PrintGuard() { printLock(); }
+    ~PrintGuard();
+    PrintGuard(const PrintGuard &) = delete;
+    PrintGuard &operator=(const PrintGuard &) = delete;
+};
+#endif
