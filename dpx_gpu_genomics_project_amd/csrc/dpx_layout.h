@@ -61,27 +61,30 @@ DPX_HD uint32_t dpx_tiled_chunk_elems(int R, int planes) { return (uint32_t)(pla
 /* Position of (plane, lane l, row-in-lane r) inside a chunk.  A lane's rows are kept in sub-tiles of at most 8 rows
  * (16 B per lane), each sub-tile a contiguous 1 KiB [lane][8] block, so every store instruction of the wave covers
  * whole 64-B sectors: for R = 16 the chunk is [plane][sub-tile 0..1][lane][8] instead of [plane][lane][16]. */
+/* (every divisor of the layouts -- R, 64R, sub-tile height, banded C and G -- is a power of two: shifts and masks, the
+ * traceback computes three of these offsets per path step) */
+DPX_HD int dpx_log2(int v) { return 31 - __builtin_clz((unsigned)v); }
 DPX_HD uint32_t dpx_tile_off(int R, int plane, int l, int r) {
-    const int Rq = R < 8 ? R : 8, Q = R / Rq;
-    return (uint32_t)(((plane * Q + r / Rq) * 64 + l) * Rq + r % Rq);
+    const int sq = R < 8 ? dpx_log2(R) : 3, Q = R >> sq; /* sub-tiles of 2^sq rows */
+    return (uint32_t)(((((plane * Q + (r >> sq)) << 6) + l) << sq) + (r & ((1 << sq) - 1)));
 }
 /* Quad layout (short queries, 4 pairs per wave): a pair's rows belong to 16 lanes, l = (i-1)/R, single stripe of 16*R
  * rows, chunk T = (j-1) + l holds [plane][sub-tile][16 lanes][<=8 rows]; n + 15 chunks per pair. */
 DPX_HD uint64_t dpx_quad_chunks(int m, int n) { return (m <= 0 || n <= 0) ? 0 : (uint64_t)n + 15u; }
 DPX_HD uint32_t dpx_quad_tile_off(int R, int plane, int l, int r) {
-    const int Rq = R < 8 ? R : 8, Q = R / Rq;
-    return (uint32_t)(((plane * Q + r / Rq) * 16 + l) * Rq + r % Rq);
+    const int sq = R < 8 ? dpx_log2(R) : 3, Q = R >> sq;
+    return (uint32_t)(((((plane * Q + (r >> sq)) << 4) + l) << sq) + (r & ((1 << sq) - 1)));
 }
 /* offset of cell (i, j) of `plane` relative to the pair's matOff */
 DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride, uint32_t lanes = 64) {
+    const int sr = dpx_log2(R), i0 = i - 1;
     if (lanes == 16) {
-        const int l = (i - 1) / R, r = (i - 1) % R;
+        const int l = i0 >> sr, r = i0 & (R - 1);
         return (uint64_t)((j - 1) + l) * (uint64_t)chunkStride + (uint64_t)dpx_quad_tile_off(R, plane, l, r);
     }
-    int i0 = i - 1;
-    int k = i0 / (64 * R);
-    int l = (i0 % (64 * R)) / R;
-    int r = i0 % R;
+    const int k = i0 >> (sr + 6);
+    const int l = (i0 >> sr) & 63;
+    const int r = i0 & (R - 1);
     uint64_t T = (uint64_t)k * (uint64_t)n + (uint64_t)(j - 1) + (uint64_t)l;
     return T * (uint64_t)chunkStride + (uint64_t)dpx_tile_off(R, plane, l, r);
 }
@@ -107,8 +110,9 @@ DPX_HD uint64_t dpx_band_index(int i, int j, int band, uint32_t chunkStride) {
     const int C = dpx_band_cpl(band), G = dpx_band_group(C);
     const int A = i + j - 2;
     const int s = (i - j + (band - 1)) >> 1;
-    const int l = s / C, c = s % C;
-    return (uint64_t)(A / G) * (uint64_t)chunkStride + (uint64_t)(l * (G * C) + (A % G) * C + c);
+    const int sc = dpx_log2(C), sg = dpx_log2(G);
+    const int l = s >> sc, c = s & (C - 1);
+    return (uint64_t)(A >> sg) * (uint64_t)chunkStride + (uint64_t)((l << (sg + sc)) + ((A & (G - 1)) << sc) + c);
 }
 
 #endif
