@@ -860,7 +860,8 @@ static int run_traceback(dpx_batch *b) {
     if (b->tbOff.empty()) {
         b->tbOff.resize(np + 1);
         uint64_t off = 0;
-        for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)(b->pairs[i].m + b->pairs[i].n + 1); }
+        /* three lines per pair, each with a dword-aligned capacity of m + n + 1 (the kernel writes aligned dwords) */
+        for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)((b->pairs[i].m + b->pairs[i].n + 1 + 3) & ~3); }
         b->tbOff[np] = off;
         const size_t need = (size_t)std::max<uint64_t>(off, 16);
         HIP_TRY(g_tbDevCache.take((void **)&b->dTb, need, &b->dTbCap));
@@ -890,7 +891,7 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
         rc = run_traceback(b);
         if (rc != DPX_OK) return rc;
     }
-    const int cap = b->pairs[pair].m + b->pairs[pair].n + 1;
+    const int cap = (b->pairs[pair].m + b->pairs[pair].n + 1 + 3) & ~3;
     const int k = b->hTbLen[pair];
     const char *base = b->hTb + b->tbOff[pair];
     char *dst[3] = {refLine, relLine, qryLine};
