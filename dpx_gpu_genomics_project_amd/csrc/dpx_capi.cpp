@@ -871,7 +871,11 @@ static int run_traceback(dpx_batch *b) {
         b->hTbLen.resize(np);
     }
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
-    HIP_TRY(dpx_launch_traceback(b->args, (int)b->numPairs, b->kernelAlgo, b->R, b->planes, b->dTbOff, b->dTb, b->dTbLen, b->stream));
+    /* enough lanes in flight to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster) */
+    bool cachedWalk = b->numPairs >= 65536;
+    if (const char *env = getenv("DPX_TB_CACHED")) cachedWalk = atoi(env) != 0; /* tests force either walk */
+    HIP_TRY(dpx_launch_traceback(b->args, (int)b->numPairs, b->kernelAlgo, b->R, b->planes, cachedWalk, b->dTbOff, b->dTb, b->dTbLen,
+                                 b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (np) {
         HIP_TRY(hipMemcpy(b->hTb, b->dTb, b->hTbBytes, hipMemcpyDeviceToHost));

@@ -40,8 +40,10 @@ hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream);
-hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, const uint64_t *tbOff,
-                                char *tb, int32_t *tbLen, hipStream_t stream);
+/* cachedWalk: LSW / LNW walk through register-resident 8-row column vectors (pays off when the batch is large enough to
+ * be bound by sector requests rather than by load latency) */
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, bool cachedWalk,
+                                const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream);
 hipError_t dpx_launch_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
                                 uint32_t *res, uint32_t *pred, hipStream_t stream);
 

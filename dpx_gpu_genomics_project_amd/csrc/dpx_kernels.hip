@@ -1437,7 +1437,90 @@ struct TbView {
     }
 };
 
-__global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R, int planes, const int32_t *endRow,
+/* A byte string read back to front through one register: four characters per aligned dword load (the walk reads
+ * query[i-1] and reference[j-1] on every step; with ~100k lanes in flight neither L1 nor L2 keeps a sector between two
+ * steps of the same lane, so every byte load was an HBM sector fetch -- profiles/README.md). */
+struct CharWin {
+    const unsigned char *s;
+    uintptr_t at = 1; /* address of the dword held in `w` (1 = none) */
+    uint32_t w = 0;
+    __device__ __forceinline__ int get(int x) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(s + x), al = a & ~(uintptr_t)3;
+        if (al != at) { at = al; w = *reinterpret_cast<const uint32_t *>(al); } /* never leaves the 256-byte aligned arena */
+        return (int)((w >> (8 * (int)(a & 3))) & 0xFFu);
+    }
+};
+
+/* The H plane seen through two registers-resident column vectors.  In the tiled and quad layouts with R >= 8 the 8 rows
+ * (i0 & ~7 .. +7) of one column are 16 contiguous, 16-byte aligned bytes: `cur` holds them for column j, `prev` for
+ * column j-1.  A path step then needs at most ONE new 16-byte load (the next column on a left / diagonal move; two when
+ * the walk climbs into the 8-row group above) instead of three 2-byte loads that each miss every cache. */
+struct TileWalker {
+    const int16_t *mat;
+    uint64_t off;
+    uint32_t cs, lanes;
+    int n, sr, border; /* sr = log2(rows per lane); border: value of H on row 0 / column 0 is border * (i + j) */
+    int i = 0, j = 0;
+    u32x4 cur, prev;
+
+    __device__ __forceinline__ u32x4 column(int i0, int jj) const { /* the 8-row group of row i0 (0-based), column jj >= 1 */
+        const int r = i0 & ((1 << sr) - 1), sub = r >> 3;
+        uint64_t T, tile;
+        if (lanes == 16) {
+            const int l = i0 >> sr;
+            T = (uint64_t)((jj - 1) + l);
+            tile = (uint64_t)(((sub << 4) + l) << 3);
+        } else {
+            const int k = i0 >> (sr + 6), l = (i0 >> sr) & 63;
+            T = (uint64_t)k * (uint64_t)n + (uint64_t)(jj - 1) + (uint64_t)l;
+            tile = (uint64_t)(((sub << 6) + l) << 3);
+        }
+        return *reinterpret_cast<const u32x4 *>(mat + off + T * (uint64_t)cs + tile);
+    }
+    static __device__ __forceinline__ int elem(const u32x4 &v, int rr) { /* int16 number rr (0..7) of the vector */
+        const uint32_t d = rr < 4 ? (rr < 2 ? v.x : v.y) : (rr < 6 ? v.z : v.w);
+        return (int)(int16_t)(d >> (16 * (rr & 1)));
+    }
+    __device__ __forceinline__ void load_both() {
+        if (i >= 1 && j >= 1) cur = column(i - 1, j);
+        if (i >= 1 && j >= 2) prev = column(i - 1, j - 1);
+    }
+    __device__ __forceinline__ void start(int i_, int j_) { i = i_; j = j_; load_both(); }
+    /* a single cell outside the two cached columns' 8-row group (the row above the group): plain 2-byte load */
+    __device__ __forceinline__ int single(int ii, int jj) const {
+        if (ii == 0 || jj == 0) return border * (ii + jj);
+        return mat[off + dpx_tiled_index(ii, jj, n, 1 << sr, 0, cs, lanes)];
+    }
+    __device__ __forceinline__ int here() const { return (i == 0 || j == 0) ? border * (i + j) : elem(cur, (i - 1) & 7); }
+    __device__ __forceinline__ int up() const {
+        if (i <= 1 || j == 0) return border * (i - 1 + j);
+        const int rr = (i - 1) & 7;
+        return rr ? elem(cur, rr - 1) : single(i - 1, j);
+    }
+    __device__ __forceinline__ int left() const {
+        if (j <= 1 || i == 0) return border * (i + j - 1);
+        return elem(prev, (i - 1) & 7);
+    }
+    __device__ __forceinline__ int diag() const {
+        if (i <= 1 || j <= 1) return border * (i - 1 + j - 1);
+        const int rr = (i - 1) & 7;
+        return rr ? elem(prev, rr - 1) : single(i - 1, j - 1);
+    }
+    __device__ __forceinline__ void move(bool rowUp, bool colLeft) {
+        const bool newGroup = rowUp && (((i - 1) & 7) == 0); /* leaving the 8-row group through its top row */
+        i -= rowUp ? 1 : 0;
+        j -= colLeft ? 1 : 0;
+        if (i == 0 || j == 0) return; /* on the border: closed form from here on */
+        if (newGroup) {
+            load_both();
+        } else if (colLeft) {
+            cur = prev;
+            if (j >= 2) prev = column(i - 1, j - 1);
+        }
+    }
+};
+
+__global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R, int planes, int cachedWalk, const int32_t *endRow,
                             const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= numPairs) return;
@@ -1466,52 +1549,90 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
         }                                                                                        \
     }
     int i = endRow[p], j = endCol[p];
-    if (algo == DPX_K_LSW || algo == DPX_K_BSW) {
+    CharWin qw{qry}, rw{ref};
+    /* register-cached columns: LSW / LNW on the tiled or quad layout with 8-row sub-tiles (rows per lane >= 8), for
+     * batches with enough lanes in flight that the walk is bound by sector requests (measured: 100k short pairs -25 %);
+     * smaller batches are bound by the latency of one dependent load per step instead, and there the plain
+     * three-loads-in-parallel step is the shorter chain (5000 x 1024^2: cached +40 %, 20k x 300^2: +10 %).  The host decides. */
+    const bool cached = (algo == DPX_K_LSW || algo == DPX_K_LNW) && v.R >= 8 && cachedWalk;
+    if (cached) {
+        const int g = a.gapOpen;
+        TileWalker w{a.mat, pr.matOff, pr.chunkStride, pr.lanes, n, dpx_log2(v.R), algo == DPX_K_LNW ? g : 0};
+        w.start(i, j);
+        if (algo == DPX_K_LSW) {
+            int h = (i > 0 && j > 0) ? w.here() : 0;
+            while (h > 0) {
+                const int up = w.up(), left = w.left();
+                if (up + g == h) { EMIT('_', ' ', qw.get(w.i - 1)); w.move(true, false); h = up; }
+                else if (left + g == h) { EMIT(rw.get(w.j - 1), ' ', '_'); w.move(false, true); h = left; }
+                else {
+                    const int dg = w.diag(), qc = qw.get(w.i - 1), rc = rw.get(w.j - 1);
+                    EMIT(rc, qc == rc ? '*' : '|', qc);
+                    w.move(true, true);
+                    h = dg;
+                }
+            }
+        } else {
+            while (w.i != 0 || w.j != 0) {
+                if (w.i == 0) { EMIT(rw.get(w.j - 1), ' ', '_'); w.move(false, true); continue; }  /* row-0 border: QUERY_INSERTION */
+                if (w.j == 0) { EMIT('_', ' ', qw.get(w.i - 1)); w.move(true, false); continue; }  /* column-0 border: QUERY_DELETION */
+                const int qc = qw.get(w.i - 1), rc = rw.get(w.j - 1);
+                const bool eq = qc == rc;
+                const int mm = w.diag() + (eq ? match : mismatch);
+                const int del = w.up() + g, ins = w.left() + g;
+                const int vmax = max(del, mm);
+                if (ins >= vmax) { EMIT(rc, ' ', '_'); w.move(false, true); }
+                else if (del >= mm) { EMIT('_', ' ', qc); w.move(true, false); }
+                else { EMIT(rc, eq ? '*' : '|', qc); w.move(true, true); }
+            }
+        }
+    } else if (algo == DPX_K_LSW || algo == DPX_K_BSW) {
         const int g = a.gapOpen;
         int h = (i > 0 && j > 0) ? v.get(i, j, 0) : 0;
         while (h > 0) {
             const int up = v.get(i - 1, j, 0), left = v.get(i, j - 1, 0), dg = v.get(i - 1, j - 1, 0);
-            if (up + g == h) { EMIT('_', ' ', qry[i - 1]); i--; h = up; }
-            else if (left + g == h) { EMIT(ref[j - 1], ' ', '_'); j--; h = left; }
-            else { EMIT(ref[j - 1], qry[i - 1] == ref[j - 1] ? '*' : '|', qry[i - 1]); i--; j--; h = dg; }
+            if (up + g == h) { EMIT('_', ' ', qw.get(i - 1)); i--; h = up; }
+            else if (left + g == h) { EMIT(rw.get(j - 1), ' ', '_'); j--; h = left; }
+            else { const int qc = qw.get(i - 1), rc = rw.get(j - 1); EMIT(rc, qc == rc ? '*' : '|', qc); i--; j--; h = dg; }
         }
     } else if (algo == DPX_K_LNW) {
         const int g = a.gapOpen;
         while (i != 0 || j != 0) {
-            if (i == 0) { EMIT(ref[j - 1], ' ', '_'); j--; continue; }  /* row-0 border: QUERY_INSERTION */
-            if (j == 0) { EMIT('_', ' ', qry[i - 1]); i--; continue; }  /* column-0 border: QUERY_DELETION */
-            const bool eq = qry[i - 1] == ref[j - 1];
+            if (i == 0) { EMIT(rw.get(j - 1), ' ', '_'); j--; continue; }  /* row-0 border: QUERY_INSERTION */
+            if (j == 0) { EMIT('_', ' ', qw.get(i - 1)); i--; continue; }  /* column-0 border: QUERY_DELETION */
+            const int qc = qw.get(i - 1), rc = rw.get(j - 1);
+            const bool eq = qc == rc;
             const int mm = v.get(i - 1, j - 1, 0) + (eq ? match : mismatch);
             const int del = v.get(i - 1, j, 0) + g, ins = v.get(i, j - 1, 0) + g;
             const int vmax = max(del, mm);
-            if (ins >= vmax) { EMIT(ref[j - 1], ' ', '_'); j--; }
-            else if (del >= mm) { EMIT('_', ' ', qry[i - 1]); i--; }
-            else { EMIT(ref[j - 1], eq ? '*' : '|', qry[i - 1]); i--; j--; }
+            if (ins >= vmax) { EMIT(rc, ' ', '_'); j--; }
+            else if (del >= mm) { EMIT('_', ' ', qc); i--; }
+            else { EMIT(rc, eq ? '*' : '|', qc); i--; j--; }
         }
     } else { /* ANW */
         const int o = a.gapOpen, e = a.gapExtend;
         int cur = 0; /* 0 SCORING, 1 INSERTION, 2 DELETION */
         while (i != 0 && j != 0) {
             if (cur == 0) {
-                const bool eq = qry[i - 1] == ref[j - 1];
+                const bool eq = qw.get(i - 1) == rw.get(j - 1);
                 const int mm = v.get(i - 1, j - 1, 0) + (eq ? match : mismatch);
                 const int D = v.get(i, j, 2), I = v.get(i, j, 1);
                 const int vmax = max(D, mm);
                 if (I >= vmax) cur = 1;
                 else if (D >= mm) cur = 2;
-                else { EMIT(ref[j - 1], eq ? '*' : '|', qry[i - 1]); i--; j--; }
+                else { EMIT(rw.get(j - 1), eq ? '*' : '|', qw.get(i - 1)); i--; j--; }
             } else if (cur == 1) {
                 const bool open = (j == 1) || (v.get(i, j - 1, 0) + o + e >= v.get(i, j - 1, 1) + e);
                 if (open) cur = 0;
-                EMIT(ref[j - 1], ' ', '_'); j--;
+                EMIT(rw.get(j - 1), ' ', '_'); j--;
             } else {
                 const bool open = (i == 1) || (v.get(i - 1, j, 0) + o + e >= v.get(i - 1, j, 2) + e);
                 if (open) cur = 0;
-                EMIT('_', ' ', qry[i - 1]); i--;
+                EMIT('_', ' ', qw.get(i - 1)); i--;
             }
         }
-        while (i > 0) { EMIT('_', ' ', qry[i - 1]); i--; }
-        while (j > 0) { EMIT(ref[j - 1], ' ', '_'); j--; }
+        while (i > 0) { EMIT('_', ' ', qw.get(i - 1)); i--; }
+        while (j > 0) { EMIT(rw.get(j - 1), ' ', '_'); j--; }
     }
 #undef EMIT
     if (pos & 3) { /* the 1-3 newest characters have not filled a dword: the newest sits in the lowest byte, at `pos` */
@@ -1728,11 +1849,11 @@ hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int alg
     return hipGetLastError();
 }
 
-hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, const uint64_t *tbOff,
-                                char *tb, int32_t *tbLen, hipStream_t stream) {
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, bool cachedWalk,
+                                const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream) {
     if (numPairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,
-                       a.endRow, a.endCol, tbOff, tb, tbLen);
+                       cachedWalk ? 1 : 0, a.endRow, a.endCol, tbOff, tb, tbLen);
     return hipGetLastError();
 }
 

@@ -70,3 +70,31 @@ def test_banded_traceback_vs_oracle(gpu):
             o = O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, band=24)
             want = ("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)
             assert b.traceback(p) == want, p
+
+
+@pytest.mark.parametrize("cached", ["0", "1"])
+@pytest.mark.parametrize("algo", ["LSW", "LNW"])
+def test_both_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
+    """Large batches walk through register-cached 8-row column vectors, small ones load cell by cell (DPX_TB_CACHED forces
+    either): 8- and 16-row tiles, several stripes, lane-group and stripe crossings, the quad layout, borders reached from
+    both sides, empty sequences -- every printed line against the oracle."""
+    monkeypatch.setenv("DPX_TB_CACHED", cached)
+    w = (3, -1, -2, -1)
+    batches = [make_batch(5, 300, 280, seed=51, first_index=96),          # R = 8, one stripe
+               make_batch(4, 700, 150, seed=52, first_index=96),          # R = 16, rows 512.. in the second sub-tile
+               make_batch(3, 40, 600, seed=53), make_batch(3, 600, 40, seed=54),
+               from_strings([("", "0123"), ("0123", ""), ("0123", "0123"), ("3", "0123012301230123"), ("0123012301230123", "3")])]
+    for r, quad in (("8", "0"), ("8", "1"), ("16", "0")):
+        monkeypatch.setenv("DPX_R", r)
+        monkeypatch.setenv("DPX_QUAD", quad)
+        extra = [make_batch(3, 64 * int(r) + 37, 200, seed=55, first_index=99)] if quad == "0" else [make_batch(9, 120, 140, seed=56), make_batch(5, 250, 90, seed=57)]
+        for sb in (batches if quad == "0" else []) + extra:
+            with gpu.Batch(CODE[algo], sb.sequences, sb.pairs, *w) as b:
+                b.fill()
+                for p in range(sb.num_pairs):
+                    refs, qry = sb.ref(p), sb.qry(p)
+                    if algo == "LSW":
+                        o = O.lsw(refs, qry, *w[:3]); want = ("", "", "") if o.score == 0 else O.lsw_traceback(refs, qry, o)
+                    else:
+                        o = O.lnw(refs, qry, *w[:3]); want = O.lnw_traceback(refs, qry, o)
+                    assert b.traceback(p) == want, (algo, cached, r, quad, p, len(qry), len(refs))

@@ -13,6 +13,9 @@ GROUPS_=(
  "TCC_EA0_WRREQ_STALL TCC_EA0_WRREQ_DRAM_CREDIT_STALL TCC_EA0_WRREQ_64B TCC_EA0_WRREQ"
  "GRBM_GUI_ACTIVE GRBM_TA_BUSY"
  "TCC_BUSY TCC_TAG_STALL TCC_NORMAL_WRITEBACK TCC_NORMAL_EVICT"
+ "TCC_HIT TCC_MISS TCC_REQ TCC_READ"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
 )
 i=0
 for g in "${GROUPS_[@]}"; do

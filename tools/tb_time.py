@@ -4,7 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpx_gpu_genomics_project_amd as dpx
 from dpx_gpu_genomics_project_amd.synth import make_ragged_batch
 dpx.init(0)
-for name, sb in (("5000 x 1024x1024", dpx.make_batch(5000, 1024, 1024, seed=1)), ("100k short", make_ragged_batch(100000, 80, 130, 100, 160, seed=6))):
+which = sys.argv[1] if len(sys.argv) > 1 else "both"
+shapes = []
+if which in ("both", "long"):
+    shapes.append(("5000 x 1024x1024", dpx.make_batch(5000, 1024, 1024, seed=1)))
+if which in ("both", "mid"):
+    shapes.append(("20000 x 300x300", dpx.make_batch(20000, 300, 300, seed=1)))
+if which in ("both", "short"):
+    shapes.append(("100k short", make_ragged_batch(100000, 80, 130, 100, 160, seed=6)))
+for name, sb in shapes:
     for algo in (dpx.ALGO_LSW, dpx.ALGO_LNW, dpx.ALGO_ANW):
         b = dpx.Batch(algo, sb.sequences, sb.pairs, 3, -1, -3 if algo == dpx.ALGO_ANW else -2, -1)
         b.fill(); b.sync(); b.traceback(0)
