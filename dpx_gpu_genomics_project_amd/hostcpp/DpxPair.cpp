@@ -1,7 +1,12 @@
 #include "DpxPair.h"
 
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <thread>
 #include <iomanip>
 #include <iostream>
 
@@ -14,45 +19,125 @@ namespace {
 }
 } // namespace
 
-void dpxAlignPair(int algo, const std::string &reference, const std::string &query, int match, int mismatch, int gapOpen,
-                  int gapExtend, int band, bool wantMatrices, DpxPairResult &out) {
-    // flat buffer in parseInput layout: reference '\0' query '\0'
-    std::string flat = reference;
-    flat.push_back('\0');
-    const int qryOff = (int)flat.size();
-    flat += query;
-    flat.push_back('\0');
-    dpx_seq_pair sp{0, (int)reference.size(), qryOff, (int)query.size()};
-    dpx_params prm{algo, match, mismatch, gapOpen, gapExtend, band};
+namespace {
 
+// One alignment request of one caller thread.
+struct Request {
+    int algo, match, mismatch, gapOpen, gapExtend, band;
+    const std::string *reference, *query;
+    DpxPairResult *out;
+    bool done = false;
+    bool sameParams(const Request &o) const {
+        return algo == o.algo && match == o.match && mismatch == o.mismatch && gapOpen == o.gapOpen && gapExtend == o.gapExtend &&
+               band == o.band;
+    }
+};
+
+// Run a group of requests (same algorithm and weights) as ONE device batch: one create / fill / results / traceback
+// round trip instead of one per pair.
+void runGroup(const std::vector<Request *> &grp, bool wantMatrices) {
+    std::string flat; // parseInput layout: reference '\0' query '\0' per pair
+    std::vector<dpx_seq_pair> pairs(grp.size());
+    size_t maxCap = 0;
+    for (size_t k = 0; k < grp.size(); k++) {
+        const std::string &r = *grp[k]->reference, &q = *grp[k]->query;
+        pairs[k].referenceIdx = (int)flat.size();
+        pairs[k].referenceSize = (int)r.size();
+        flat += r;
+        flat.push_back('\0');
+        pairs[k].queryIdx = (int)flat.size();
+        pairs[k].querySize = (int)q.size();
+        flat += q;
+        flat.push_back('\0');
+        maxCap = std::max(maxCap, r.size() + q.size() + 2);
+    }
+    const Request &first = *grp[0];
+    dpx_params prm{first.algo, first.match, first.mismatch, first.gapOpen, first.gapExtend, first.band};
     dpx_batch *b = nullptr;
-    int rc = dpx_batch_create(&prm, flat.data(), flat.size(), &sp, 0, 1, DPX_KEEP_MATRICES, &b);
+    int rc = dpx_batch_create(&prm, flat.data(), flat.size(), pairs.data(), 0, grp.size(), DPX_KEEP_MATRICES, &b);
     if (rc != DPX_OK) fail("dpx_batch_create", rc);
     if ((rc = dpx_batch_fill(b, nullptr)) != DPX_OK) fail("dpx_batch_fill", rc);
-    int32_t score = 0, er = 0, ec = 0;
-    if ((rc = dpx_batch_results(b, &score, &er, &ec)) != DPX_OK) fail("dpx_batch_results", rc);
-    out.score = score;
-    out.endRow = er;
-    out.endCol = ec;
-    const size_t cap = reference.size() + query.size() + 2;
-    std::vector<char> l0(cap), l1(cap), l2(cap);
-    int32_t len = 0;
-    if ((rc = dpx_batch_traceback(b, 0, l0.data(), l1.data(), l2.data(), &len)) != DPX_OK) fail("dpx_batch_traceback", rc);
-    out.refLine.assign(l0.data(), (size_t)len);
-    out.relLine.assign(l1.data(), (size_t)len);
-    out.qryLine.assign(l2.data(), (size_t)len);
-    if (wantMatrices) {
-        const size_t cells = (reference.size() + 1) * (query.size() + 1);
-        out.H.resize(cells);
-        if ((rc = dpx_batch_matrix(b, 0, DPX_MAT_H, out.H.data())) != DPX_OK) fail("dpx_batch_matrix(H)", rc);
-        if (algo == DPX_ALGO_ANW) {
-            out.I.resize(cells);
-            out.D.resize(cells);
-            if ((rc = dpx_batch_matrix(b, 0, DPX_MAT_I, out.I.data())) != DPX_OK) fail("dpx_batch_matrix(I)", rc);
-            if ((rc = dpx_batch_matrix(b, 0, DPX_MAT_D, out.D.data())) != DPX_OK) fail("dpx_batch_matrix(D)", rc);
+    std::vector<int32_t> score(grp.size()), er(grp.size()), ec(grp.size());
+    if ((rc = dpx_batch_results(b, score.data(), er.data(), ec.data())) != DPX_OK) fail("dpx_batch_results", rc);
+    std::vector<char> l0(maxCap), l1(maxCap), l2(maxCap);
+    for (size_t k = 0; k < grp.size(); k++) {
+        DpxPairResult &out = *grp[k]->out;
+        out.score = score[k];
+        out.endRow = er[k];
+        out.endCol = ec[k];
+        int32_t len = 0;
+        if ((rc = dpx_batch_traceback(b, k, l0.data(), l1.data(), l2.data(), &len)) != DPX_OK) fail("dpx_batch_traceback", rc);
+        out.refLine.assign(l0.data(), (size_t)len);
+        out.relLine.assign(l1.data(), (size_t)len);
+        out.qryLine.assign(l2.data(), (size_t)len);
+        if (wantMatrices) {
+            const size_t cells = (grp[k]->reference->size() + 1) * (grp[k]->query->size() + 1);
+            out.H.resize(cells);
+            if ((rc = dpx_batch_matrix(b, k, DPX_MAT_H, out.H.data())) != DPX_OK) fail("dpx_batch_matrix(H)", rc);
+            if (first.algo == DPX_ALGO_ANW) {
+                out.I.resize(cells);
+                out.D.resize(cells);
+                if ((rc = dpx_batch_matrix(b, k, DPX_MAT_I, out.I.data())) != DPX_OK) fail("dpx_batch_matrix(I)", rc);
+                if ((rc = dpx_batch_matrix(b, k, DPX_MAT_D, out.D.data())) != DPX_OK) fail("dpx_batch_matrix(D)", rc);
+            }
         }
     }
     dpx_batch_destroy(b);
+}
+
+// The reference's driver aligns one pair per call from 20 threads (c++/main.cpp:18-19,203).  A GPU round trip costs
+// ~0.2 ms whatever the number of pairs in it, so concurrent callers are combined: the first thread to arrive becomes the
+// leader, lets the others queue up for a moment, runs everybody's pairs as one device batch and hands the results
+// back.  Same results, same stdout; the per-pair cost drops by about the number of threads.
+std::mutex g_mu;
+std::condition_variable g_cv;
+std::vector<Request *> g_queue;
+bool g_leaderActive = false;
+
+void gatherWindow(std::unique_lock<std::mutex> &lk) {
+    // wait while callers keep arriving: stop after 40 us without a new request, 400 us in total at most
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    auto lastArrival = t0;
+    size_t seen = g_queue.size();
+    for (;;) {
+        lk.unlock();
+        std::this_thread::yield();
+        lk.lock();
+        const auto now = clock::now();
+        if (g_queue.size() != seen) { seen = g_queue.size(); lastArrival = now; }
+        if (now - lastArrival > std::chrono::microseconds(40) || now - t0 > std::chrono::microseconds(400)) return;
+    }
+}
+
+} // namespace
+
+void dpxAlignPair(int algo, const std::string &reference, const std::string &query, int match, int mismatch, int gapOpen,
+                  int gapExtend, int band, bool wantMatrices, DpxPairResult &out) {
+    Request rq{algo, match, mismatch, gapOpen, gapExtend, band, &reference, &query, &out};
+    if (wantMatrices) { // matrix dumps (PRINT_MATRIX builds, print_matrix()): one pair, its own batch
+        runGroup({&rq}, true);
+        return;
+    }
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_queue.push_back(&rq);
+    for (;;) { // follower: sleep until a leader has served this request, or until there is no leader
+        if (rq.done) return;
+        if (!g_leaderActive) break;
+        g_cv.wait(lk);
+    }
+    g_leaderActive = true;
+    gatherWindow(lk);
+    // serve everything queued with this request's parameters (this request included), then retire
+    std::vector<Request *> grp, rest;
+    for (Request *r : g_queue) (r->sameParams(rq) ? grp : rest).push_back(r);
+    g_queue.swap(rest);
+    lk.unlock();
+    runGroup(grp, false);
+    lk.lock();
+    for (Request *r : grp) r->done = true;
+    g_leaderActive = false;
+    g_cv.notify_all(); // served followers return; one of the others (if any) becomes the next leader
 }
 
 void dpxPrintScoreMatrix(const std::string &reference, const std::string &query, const std::vector<short> &M) {

@@ -1,6 +1,7 @@
-// DpxPair.h -- the one place where the C++ host mirror touches the engine: run ONE pair through the C ABI
-// (include/dpx_align.h).  Used by the SequenceAligner-derived classes' score_matrix().  Thread-safe and re-entrant
-// (every call owns its dpx_batch), as the reference's 20-pthread driver requires (c++/main.cpp:18-19,203).
+// DpxPair.h -- the one place where the C++ host mirror touches the engine: run a pair through the C ABI
+// (include/dpx_align.h).  Used by the SequenceAligner-derived classes' score_matrix().  Thread-safe and re-entrant, as
+// the reference's 20-pthread driver requires (c++/main.cpp:18-19,203); calls that arrive from several threads at about
+// the same time are combined into one device batch (DpxPair.cpp), which is what makes the per-pair classes usable.
 // Errors follow the reference's convention: message on stderr, exit(1) (c++/parseInput.cpp:12-15, cuda handleErrs()).
 #pragma once
 #include <string>

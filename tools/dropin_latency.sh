@@ -15,6 +15,8 @@ for exe in oracle/_ref/main_dropin_LNW "dpx_gpu_genomics_project_amd/hostcpp/dpx
 done
 echo "== reference CPU classes (oracle/_ref/ref_driver_O2 align mode)"
 oracle/_ref/ref_driver_O2 time LNW /tmp/p4000.txt 3 -1 -2 -1 4000
+echo "== reference CPU classes as the reference builds them (-O0)"
+oracle/_ref/ref_driver time LNW /tmp/p4000.txt 3 -1 -2 -1 4000
 echo "== phase trace of one thread's first pairs (DPX_TRACE=1)"
 head -c 3000 /tmp/p4000.txt > /dev/null
 python - <<PY
