@@ -257,6 +257,10 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                          "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1)},
         }
+        if algo_name == "BSW":  # GCUPS counts refLen x queryLen as the reference does; also give the in-band rate
+            inband = (info["algorithmic_bytes"] - npairs * (m + n + 28)) // 2
+            out["roofline"]["in_band_cells_per_launch"] = inband
+            out["roofline"]["in_band_kernel_gcups"] = round(inband / (kernel_ms * 1e-3) / 1e9, 1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend,
                                                args.cpu_pairs if m else npairs, shape)
