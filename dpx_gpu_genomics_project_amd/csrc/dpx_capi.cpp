@@ -50,6 +50,9 @@ int bind_device() {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* LDS request that caps residency at 16 fill waves per CU (9 KiB per wave of the workgroup) */
+constexpr size_t kLdsFloor = 36u * 1024u * (DPX_FILL_THREADS / 64) / 4;
+
 /* Parked buffers.  The matrix pool is by far the largest allocation (22 GB for the headline batch) and hipMalloc/hipFree
  * of that size cost 50-1000 ms -- the "memory management" slice that dominated the reference's V12 profile (187 of 440 ms)
  * and that it attacked by pooling (V9) and sizing once (V14); pinning ~70 MB of host memory costs ~10 ms; and even the
@@ -464,7 +467,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
     /* Store-bound fills run ~2 % faster with 3-4 waves per SIMD than with 6-7 (fewer write streams in flight,
      * profiles/README.md): cap residency at 4 workgroups per CU through the LDS request. */
-    if (b->store && !banded && b->ldsBytes < 36u * 1024u) b->ldsBytes = 36u * 1024u;
+    if (b->store && !banded && b->ldsBytes < kLdsFloor) b->ldsBytes = kLdsFloor;
     if (const char *env = getenv("DPX_LDS_PAD")) b->ldsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 
@@ -711,7 +714,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         a.ldsQryOff = (uint32_t)(edgeBytes + refB);
         a.ldsBufStride = (uint32_t)(refB + qB);
         a.ldsPerWave = (uint32_t)(edgeBytes + 2 * (refB + qB));
-        b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), 36u * 1024u);
+        b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), kLdsFloor);
         if (b->streamLds > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
     if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
@@ -735,7 +738,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         k.ldsBufStride = (uint32_t)refStride;
         k.ldsPerWave = (uint32_t)(4 * refStride);
         b->pkLdsBytes = 4 * refStride * (DPX_FILL_THREADS / 64);
-        if (b->store && b->pkLdsBytes < 36u * 1024u) b->pkLdsBytes = 36u * 1024u; /* store-bound: 4 workgroups per CU (see above) */
+        if (b->store && b->pkLdsBytes < kLdsFloor) b->pkLdsBytes = kLdsFloor; /* store-bound: 16 waves per CU (see above) */
         if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
         b->q16Args = k;

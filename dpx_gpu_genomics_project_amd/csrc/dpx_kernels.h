@@ -14,7 +14,9 @@
 #define DPX_K_BSW 3
 
 /* one wave per pair; DPX_FILL_THREADS/64 independent waves share a workgroup (no barriers between them) */
+#ifndef DPX_FILL_THREADS
 #define DPX_FILL_THREADS 256
+#endif
 
 
 typedef struct dpx_fill_args {
