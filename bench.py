@@ -61,15 +61,14 @@ def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pa
     from dpx_gpu_genomics_project_amd.synth import SynthBatch, write_pairs_file
 
     cores = os.cpu_count() or 1
-    npairs = min(budget_pairs, sb.num_pairs)
-    end = int(sb.pairs["queryIdx"][npairs - 1] + sb.pairs["querySize"][npairs - 1] + 1)
-    sample = SynthBatch(sb.sequences[:end], sb.pairs[:npairs], sb.m, sb.n)
-    ref_o2 = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
-    ref_o0 = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    desc = f"first {npairs} pairs of the rank-0 batch ({shape}), fill = init_matrix+score_matrix"
     if algo_name == "BSW":
         budget_pairs = min(budget_pairs, 64)  # the banded oracle walks 4096 rows x 255 cells per pair
     npairs = min(budget_pairs, sb.num_pairs)
+    end = int(sb.pairs["queryIdx"][npairs - 1] + sb.pairs["querySize"][npairs - 1] + 1)
+    sample = SynthBatch(sb.sequences[:end], sb.pairs[:npairs], sb.m, sb.n)  # exactly the pairs that are timed
+    ref_o2 = os.path.join(ROOT, "oracle", "_ref", "ref_driver_O2")
+    ref_o0 = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    desc = f"first {npairs} pairs of the rank-0 batch ({shape}), fill = init_matrix+score_matrix"
     if os.path.exists(ref_o2) and algo_name in ("LSW", "LNW", "ANW"):
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "sample.txt")
@@ -107,11 +106,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="lsw_10k_1024", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (debug)")
+    ap.add_argument("--total-pairs", type=int, default=0, help="override the total pair count of a sharded (strong-scaling) workload (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4000, help="pairs of the CPU-baseline sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only; RCCL refuses this)")
+    ap.add_argument("--dump-scores", default="", help="tests: every rank saves its local scores to PREFIX.rank<r>.npy, rank 0 "
+                    "the gathered vector to PREFIX.gathered.npy (after the timed region)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +145,8 @@ def main():
 
     algo_name, npairs, m, n, match, mismatch, gap_open, gap_extend, seed = WORKLOADS[args.workload]
     strong = npairs < 0  # negative = total over all ranks: each rank takes its contiguous ceil(N/G)-sized shard
+    if strong and args.total_pairs:
+        npairs = -args.total_pairs
     if strong:
         from dpx_gpu_genomics_project_amd.shard import shard_range
         lo, hi = shard_range(-npairs, rank, world)
@@ -226,12 +230,17 @@ def main():
         assert last is not None and last.numel() == npairs * world
         assert torch.equal(last[:npairs].cpu(), torch.from_numpy(scores))
 
+    if args.dump_scores:
+        np.save(f"{args.dump_scores}.rank{rank}.npy", scores)
+        if rank == 0 and world > 1:
+            np.save(f"{args.dump_scores}.gathered.npy", last.cpu().numpy())
+
     if rank == 0:
         shape = f"{m}x{n}" if m else "short-read (reference 100-160 x query 80-130)"
-        # arithmetic type of the kernel the engine picks for this batch (dpx_capi.cpp): equal-shaped LSW/LNW pairs whose
-        # query fits one stripe run two per wave on the packed-int16 pipe (v_pk_*_i16), everything else in int32
-        packed = algo_name in ("LSW", "LNW") and 0 < m <= 1024 and npairs >= 4096 and os.environ.get("DPX_PACKED", "1") != "0"
-        dtype = "int16" if packed else "int32"
+        # arithmetic type of the kernel the engine picked for this batch (dpx_batch_describe): equal-shaped LSW/LNW pairs
+        # whose query fits one stripe run two per wave on the packed-int16 pipe (v_pk_*_i16), everything else in int32
+        desc = batch.describe()
+        dtype = desc["dtype"]
         total_cells = info["cells"] * world
         value = total_cells * args.steps / elapsed / 1e9
         achieved = info["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
@@ -251,7 +260,8 @@ def main():
                        "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
                        "parallelism": f"{world} rank(s), 1 per GPU, pairs sharded, RCCL gather of int32 scores" if world > 1 else "1 GPU",
                        "cells_per_gpu": info["cells"], "matrix_bytes_per_gpu": info["matrix_bytes"],
-                       "precondition_fills": precondition_fills},
+                       "precondition_fills": precondition_fills, "kernel": desc["kernel"],
+                       "rows_per_lane": desc["rows_per_lane"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],

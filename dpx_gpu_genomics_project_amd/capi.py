@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_strerror", "dpx_last_error",
     "dpx_abi_version", "dpx_batch_create", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_sync",
     "dpx_batch_device_results", "dpx_batch_results", "dpx_batch_matrix", "dpx_batch_traceback",
-    "dpx_batch_info", "dpx_batch_destroy", "dpx_align_batch", "dpx_prim_eval",
+    "dpx_batch_info", "dpx_batch_describe", "dpx_batch_destroy", "dpx_align_batch", "dpx_prim_eval",
 )
 
 
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.dpx_batch_traceback.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, i32p]
     lib.dpx_batch_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64)]
+    lib.dpx_batch_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.dpx_batch_destroy.argtypes = [vp]
     lib.dpx_align_batch.argtypes = [C.POINTER(Params), vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     lib.dpx_prim_eval.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp]
@@ -180,6 +181,13 @@ class Batch:
                "dpx_batch_info")
         return {"num_pairs": npairs.value, "cells": cells.value, "matrix_bytes": mb.value,
                 "algorithmic_bytes": ab.value}
+
+    def describe(self) -> dict:
+        """How the engine fills this batch (dpx_batch_describe): kernel, arithmetic type, launch-list sizes."""
+        buf = C.create_string_buffer(512)
+        _check(self._lib.dpx_batch_describe(self._h, buf, 512), "dpx_batch_describe")
+        out = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+        return {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in out.items()}
 
     def close(self) -> None:
         if self._h and self._h.value:

@@ -251,6 +251,7 @@ struct dpx_batch {
     size_t dTbCap = 0, hTbCap = 0; /* capacities of the (possibly recycled) buffers */
     std::vector<int32_t> hTbLen;
     bool tbValid = false;
+    size_t nSingles = 0, nCouples = 0, nQuad8 = 0, nQuad16 = 0; /* launch-list sizes (dpx_batch_describe) */
 };
 
 extern "C" {
@@ -323,6 +324,12 @@ static int validate_params(const dpx_params *p) {
     if (!p) return DPX_ERR_INVALID;
     if (p->algo < DPX_ALGO_LNW || p->algo > DPX_ALGO_BSW) return DPX_ERR_INVALID;
     if (p->algo == DPX_ALGO_BSW && p->band < 1) return DPX_ERR_INVALID;
+    /* the int32 kernels add a weight to a cell value (|H| <= 32767 after fits_int16) and to the affine kernels' virtual
+     * -2^29 borders: weights beyond +-2^20 could wrap those sums (and no int16 matrix could hold what they produce) */
+    const long long lim = 1ll << 20;
+    for (long long w : {(long long)p->match, (long long)p->mismatch, (long long)p->gapOpen,
+                        p->algo == DPX_ALGO_ANW ? (long long)p->gapExtend : 0ll})
+        if (w > lim || w < -lim) return DPX_ERR_RANGE;
     return DPX_OK;
 }
 
@@ -346,6 +353,22 @@ static bool fits_int16(const dpx_params &p, long long m, long long n) {
     const long long loH = 2 * neg(o) + neg(e) * (m + n), hiH = diag + (pos(o) + pos(e)) * (m + n);
     const long long lo = loH + neg(o + e), hi = hiH + pos(o) + pos(e) * std::max(m, n);
     return lo >= -lim && hi <= lim;
+}
+
+/* The "+Opt" packed kernel (k_linear_fill_pk) does EVERY add in wrapping 16-bit halves (v_pk_add_i16 / v_pk_mad_i16), so
+ * not only the stored H values but the weights themselves and the intermediates `diag + s` and `max(up, left) + gap`
+ * must stay inside int16: H lies in [lo, hi] (fits_int16's bounds), an intermediate is one weight away from an H value
+ * or a border value.  Batches that fail this run on the int32 kernels (same results, whatever the batch size). */
+static bool packed_safe(const dpx_params &p, long long m, long long n) {
+    if (p.algo != DPX_ALGO_LNW && p.algo != DPX_ALGO_LSW && p.algo != DPX_ALGO_BSW) return false;
+    auto pos = [](long long v) { return v > 0 ? v : 0; };
+    auto neg = [](long long v) { return v < 0 ? v : 0; };
+    const long long wmin = std::min<long long>({p.match, p.mismatch, p.gapOpen, 0}), wmax = std::max<long long>({p.match, p.mismatch, p.gapOpen, 0});
+    if (wmin < -32768 || wmax > 32767) return false;
+    const long long diag = pos(std::max<long long>(p.match, p.mismatch)) * std::min(m, n);
+    const long long hi = diag + pos(p.gapOpen) * (m + n);
+    const long long lo = p.algo == DPX_ALGO_LNW ? neg(p.gapOpen) * (m + n) : 0;
+    return lo + wmin >= -32768 && hi + wmax <= 32767 && n <= 65535;
 }
 
 /* cells (i, j) with 1 <= i <= m, 1 <= j <= n, |i - j| <= B - 1: sum over the rows of min(n, i+B-1) - max(1, i-B+1) + 1 */
@@ -552,6 +575,15 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     if (b->quad) usePacked = false;
     else
     if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
+    /* 16-bit wrapping arithmetic: only when weights and every intermediate provably fit (also under DPX_PACKED=1) */
+    if (usePacked) {
+        dpx_params kp = *params;
+        kp.algo = kernelAlgo;
+        usePacked = packed_safe(kp, b->maxM, b->maxN);
+        /* 4-byte edge entries + 2-byte reference entries per wave: very long references do not fit the LDS twice over */
+        const size_t pkNeed = (align_up((size_t)(b->maxN + 2) * 4, 16) + align_up(((size_t)b->maxN + 128) * 2, 16)) * (DPX_FILL_THREADS / 64);
+        if (pkNeed > 160u * 1024u) usePacked = false;
+    }
     if (usePacked) {
         std::vector<int32_t> idx;
         idx.reserve(numPairs);
@@ -745,6 +777,10 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->q16Args.order = b->dCouples + numQuad8;
         b->q16Args.numPairs = (int32_t)(couples.size() - numQuad8);
     }
+    b->nSingles = numSingles;
+    b->nCouples = b->packed ? numCouples : 0;
+    b->nQuad8 = b->quad ? numQuad8 : 0;
+    b->nQuad16 = b->quad ? couples.size() - numQuad8 : 0;
     *out = b;
     return DPX_OK;
 }
@@ -781,20 +817,18 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     if (!b || repeats < 1 || !usecPerFill) return DPX_ERR_INVALID;
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, b->stream));
-    for (int i = 0; i < repeats; i++) {
-        hipError_t e = launch_all(b, b->stream);
-        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hip_fail(e, "dpx_launch_fill"); }
-    }
-    HIP_TRY(hipEventRecord(e1, b->stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, b->stream);
+    for (int i = 0; i < repeats && e == hipSuccess; i++) e = launch_all(b, b->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, b->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0); /* on every path */
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return hip_fail(e, "dpx_batch_fill_timed");
     *usecPerFill = (double)ms * 1000.0 / repeats;
     b->lastStream = b->stream;
     b->filled = true;
@@ -860,18 +894,19 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
 static int run_traceback(dpx_batch *b) {
     if (b->tbValid) return DPX_OK;
     const size_t np = b->numPairs;
-    if (b->tbOff.empty()) {
-        b->tbOff.resize(np + 1);
+    if (b->tbOff.empty() || !b->dTb || !b->hTb) { /* (a failed earlier attempt leaves tbOff empty: set up again) */
+        std::vector<uint64_t> offs(np + 1);
         uint64_t off = 0;
         /* three lines per pair, each with a dword-aligned capacity of m + n + 1 (the kernel writes aligned dwords) */
-        for (size_t i = 0; i < np; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)((b->pairs[i].m + b->pairs[i].n + 1 + 3) & ~3); }
-        b->tbOff[np] = off;
+        for (size_t i = 0; i < np; i++) { offs[i] = off; off += 3ull * (uint64_t)((b->pairs[i].m + b->pairs[i].n + 1 + 3) & ~3); }
+        offs[np] = off;
         const size_t need = (size_t)std::max<uint64_t>(off, 16);
-        HIP_TRY(g_tbDevCache.take((void **)&b->dTb, need, &b->dTbCap));
-        HIP_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!b->dTb) HIP_TRY(g_tbDevCache.take((void **)&b->dTb, need, &b->dTbCap));
+        HIP_TRY(hipMemcpy(b->dTbOff, offs.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!b->hTb) HIP_TRY(g_tbHostCache.take((void **)&b->hTb, need, &b->hTbCap));
         b->hTbBytes = off;
-        HIP_TRY(g_tbHostCache.take((void **)&b->hTb, need, &b->hTbCap));
         b->hTbLen.resize(np);
+        b->tbOff.swap(offs); /* only now: every buffer the later calls rely on exists */
     }
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     /* enough lanes in flight to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster) */
@@ -905,6 +940,18 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
     for (int l = 0; l < 3; l++)
         if (dst[l]) { memcpy(dst[l], base + (size_t)l * cap + (cap - k), (size_t)k); dst[l][k] = 0; }
     if (len) *len = k;
+    return DPX_OK;
+}
+
+int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
+    if (!b || !buf || !cap) return DPX_ERR_INVALID;
+    static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
+    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? "k_banded_fill" : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_quad" : "k_affine_fill")
+                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_quad" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+    /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
+    snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu quad8=%zu quad16=%zu singles=%zu streams=%d",
+             names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nQuad8,
+             b->nQuad16, b->nSingles, (int)b->args.numStreams);
     return DPX_OK;
 }
 

@@ -136,6 +136,12 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
  * bytes of HBM the matrices occupy, algorithmic bytes of one fill. */
 int dpx_batch_info(dpx_batch *b, size_t *numPairs, uint64_t *cells, uint64_t *matrixBytes, uint64_t *algorithmicBytes);
 
+/* One line of text about how the batch will be (was) filled: `algo=LSW kernel_algo=LSW kernel=k_linear_fill_pk dtype=int16
+ * rows_per_lane=16 store=1 couples=5000 quad8=0 quad16=0 singles=0 streams=0`.  The reference prints its launch
+ * geometry the same way (cuda/LNW/LinearNeedlemanWunschV19.cu:398-409); tests and bench.py read the kernel and the
+ * arithmetic type from here instead of guessing the host's choice. */
+int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap);
+
 int dpx_batch_destroy(dpx_batch *b);
 
 /* ---- one-shot path (what the SequenceAligner-derived classes call from score_matrix()) ------------- */

@@ -48,3 +48,102 @@ def test_packed_ragged_mix_and_empty(gpu, algo, monkeypatch):
 def test_packed_headline_shape(gpu, monkeypatch):
     monkeypatch.setenv("DPX_PACKED", "1")
     _check(gpu, "LSW", make_batch(6, 1024, 1024, seed=1, first_index=95), (3, -1, -2), every=2)
+
+
+# ---- round 2: the packed pipe under fuzz weights / alphabets and at the int16 limits fits_int16() admits ----
+
+def _uniform(rng, count, m, n, alphabet, related=0.6):
+    """`count` pairs of one shape (the packed kernel couples equal-shaped pairs), arbitrary byte alphabet."""
+    pairs = []
+    for _ in range(count):
+        ref = rng.choice(alphabet, size=n).astype(np.uint8)
+        if rng.random() < related and m and n:
+            q = np.resize(ref, m).copy()
+            flip = rng.random(m) < 0.15
+            q[flip] = rng.choice(alphabet, size=int(flip.sum()))
+        else:
+            q = rng.choice(alphabet, size=m).astype(np.uint8)
+        pairs.append((ref.tobytes(), q.tobytes()))
+    return from_strings(pairs)
+
+
+FUZZ_WEIGHTS = [(3, -1, -2), (1, -1, -1), (2, -3, 0), (0, 0, 0), (5, 2, -4), (1, -2, 1), (7, -5, -9)]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("algo", ["LSW", "LNW"])
+def test_packed_fuzz(gpu, algo, seed, monkeypatch):
+    """tests/test_gpu_fuzz.py's weights and alphabets with DPX_PACKED=1 (its 24-pair ragged batches never couple)."""
+    monkeypatch.setenv("DPX_PACKED", "1")
+    rng = np.random.default_rng(7000 + 10 * seed + len(algo))
+    code = {"LNW": gpu.ALGO_LNW, "LSW": gpu.ALGO_LSW}[algo]
+    for wi, w in enumerate(FUZZ_WEIGHTS):
+        alphabet = [np.array([48, 49, 50, 51], np.uint8), np.arange(256, dtype=np.uint8), np.array([0, 255], np.uint8)][wi % 3]
+        m, n = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        sb = _uniform(rng, 7, m, n, alphabet)
+        with gpu.Batch(code, sb.sequences, sb.pairs, *w) as b:
+            d = b.describe()
+            assert d["kernel"] == "k_linear_fill_pk" and d["couples"] == 3 and d["singles"] == 1, d
+        _check(gpu, algo, sb, w)
+
+
+def test_packed_int16_edges(gpu, monkeypatch):
+    """Shapes and weights at the limits the range check admits, on the 16-bit wrapping pipe."""
+    monkeypatch.setenv("DPX_PACKED", "1")
+    rng = np.random.default_rng(99)
+    acgt = np.array([48, 49, 50, 51], np.uint8)
+    # 4096 x 4096 identical pair: LSW score 3 * 4096 = 12288 (four 1024-row stripes on the packed kernel)
+    ref = rng.choice(acgt, size=4096).astype(np.uint8).tobytes()
+    other = rng.choice(acgt, size=4096).astype(np.uint8).tobytes()
+    sb = from_strings([(ref, ref), (ref, other)])
+    with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, 3, -1, -2) as b:
+        assert b.describe()["kernel"] == "k_linear_fill_pk"
+        b.fill()
+        sc, er, ec = b.results()
+        assert (sc[0], er[0], ec[0]) == (12288, 4096, 4096)
+    _check(gpu, "LSW", sb, (3, -1, -2))
+    # LNW, gap -3 on long dissimilar pairs: border H[m][0] = -3 * 5400 = -16200, corner cells near -32400 + ...
+    sb = _uniform(rng, 2, 5400, 5400, acgt, related=0.0)
+    with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, 3, -1, -3) as b:
+        assert b.describe()["kernel"] == "k_linear_fill_pk"
+    _check(gpu, "LNW", sb, (3, -1, -3))
+    # LNW borders next to the int16 floor: H[0][6500] = H[6500][0] = -5 * 6500 = -32500 (gap * (m + n) = -32750)
+    for shape in ((6500, 50), (50, 6500)):
+        sb = from_strings([(b"0" * shape[0], b"1" * shape[1]), (b"2" * shape[0], b"3" * shape[1])])
+        with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, 1, -1, -5) as b:
+            assert b.describe()["kernel"] == "k_linear_fill_pk"
+            b.fill()
+            assert b.matrix(0).min() == -32500
+        _check(gpu, "LNW", sb, (1, -1, -5), every=1)
+    # positive gap and mismatch > match (every path collects on every step)
+    sb = _uniform(rng, 4, 700, 900, acgt)
+    _check(gpu, "LSW", sb, (3, 5, 4))
+    _check(gpu, "LNW", sb, (2, 7, 6))
+
+
+def test_packed_is_refused_where_16_bit_adds_would_wrap(gpu, monkeypatch):
+    """weights the API accepts but whose intermediates leave int16 must NOT take the packed pipe -- the
+    int32 kernels fill the batch (same answers whatever the batch size), also under DPX_PACKED=1."""
+    monkeypatch.setenv("DPX_PACKED", "1")
+    rng = np.random.default_rng(5)
+    acgt = np.array([48, 49, 50, 51], np.uint8)
+    sb = _uniform(rng, 6, 300, 280, acgt)
+    for algo, w in (("LSW", (3, -40000, -2)), ("LNW", (3, -40000, -2)), ("LSW", (3, -1, -50000))):
+        code = {"LNW": gpu.ALGO_LNW, "LSW": gpu.ALGO_LSW}[algo]
+        with gpu.Batch(code, sb.sequences, sb.pairs, *w) as b:
+            assert b.describe()["kernel"] == "k_linear_fill", (algo, w)
+        _check(gpu, algo, sb, w)
+    # LNW, gap -8, mismatch -20000, 1024 x 1024 dissimilar: H reaches about -13000 and H + mismatch < -32768
+    sb = _uniform(rng, 4, 1024, 1024, acgt, related=0.0)
+    with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, 3, -20000, -8) as b:
+        assert b.describe()["kernel"] == "k_linear_fill"
+    _check(gpu, "LNW", sb, (3, -20000, -8), every=2)
+    # and what no int16 cell can hold is an error, never a wrapped matrix
+    big = from_strings([(b"0" * 4096, b"0" * 4096)] * 2)
+    for algo, w in ((gpu.ALGO_LSW, (9, -1, -2)), (gpu.ALGO_LNW, (3, -1, -5)), (gpu.ALGO_LSW, (3, -1, 3))):
+        with pytest.raises(gpu.DpxError) as e:
+            gpu.Batch(algo, big.sequences, big.pairs, *w)
+        assert e.value.status == -4  # DPX_ERR_RANGE
+    with pytest.raises(gpu.DpxError) as e:
+        gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, 3, -(1 << 21), -2)
+    assert e.value.status == -4
