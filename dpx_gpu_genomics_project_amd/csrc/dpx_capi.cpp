@@ -228,6 +228,8 @@ struct dpx_batch {
     int16_t *dMat = nullptr;
     int32_t *dScore = nullptr, *dEndRow = nullptr, *dEndCol = nullptr;
     hipStream_t stream = nullptr;     /* the batch's own stream */
+    hipStream_t sideStream = nullptr; /* secondary kernels of a fill run here, concurrently with the main one (launch_all) */
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
     size_t ldsBytes = 0;
@@ -240,7 +242,7 @@ struct dpx_batch {
     dpx_fill_args q16Args{};
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
-    size_t pkLdsBytes = 0;
+    size_t pkLdsBytes = 0, q16LdsBytes = 0;
     /* traceback (lazy): device line buffers + host mirror */
     uint64_t *dTbOff = nullptr;
     char *dTb = nullptr;
@@ -389,6 +391,9 @@ int dpx_batch_destroy(dpx_batch *b) {
     /* buffers are parked for the next batch, not freed: nothing of this batch may still be running on them */
     if (b->lastStream && b->lastStream != b->stream) (void)hipStreamSynchronize(b->lastStream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); stream_park(b->stream); }
+    if (b->sideStream) { (void)hipStreamSynchronize(b->sideStream); stream_park(b->sideStream); }
+    if (b->evFork) (void)hipEventDestroy(b->evFork);
+    if (b->evJoin) (void)hipEventDestroy(b->evJoin);
     g_arenaCache.park(b->arena, b->arenaCap);
     g_matCache.park(b->dMat, b->matPoolBytes);
     g_tbDevCache.park(b->dTb, b->dTbCap);
@@ -663,7 +668,6 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 4096) group = v; }
         const uint32_t chunkElems = banded ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
         auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
-            if (pd.lanes == 16) return dpx_quad_chunks(pd.m, pd.n);
             return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
         };
         uint64_t off = 0;
@@ -699,9 +703,13 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
                 off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
             }
         } else if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave = two adjacent slots */
-        else if (b->quad) { /* one wave = four adjacent slots */
-            place(std::vector<int32_t>(couples.begin(), couples.begin() + numQuad8), (size_t)group * 4, 16u * 8u * (uint32_t)b->planes);
-            place(std::vector<int32_t>(couples.begin() + numQuad8, couples.end()), (size_t)group * 4, 16u * 16u * (uint32_t)b->planes);
+        else if (b->quad) { /* 8 x 8 tile layout (dpx_layout.h): every pair a contiguous run of whole 128-byte lines, in launch order */
+            for (int32_t c : couples) {
+                dpx_pair_dev &pd = b->pairs[c];
+                pd.matOff = off;
+                pd.chunkStride = dpx_tile8_chunk_elems(pd.m, b->planes);
+                off += dpx_tile8_col_blocks(pd.m, pd.n) * (uint64_t)pd.chunkStride;
+            }
         }
         if (b->streamed) {
         } else if (b->packed || b->quad || !singles.empty()) {
@@ -761,21 +769,30 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if (b->quad) { /* per wave: four staged references [16 + n + 32] */
-        dpx_fill_args &k = b->pkArgs;
-        k = a;
-        k.order = b->dCouples;
-        k.numPairs = (int32_t)numQuad8;
-        const size_t refStride = align_up((size_t)b->maxN + 48, 16);
-        k.ldsBufStride = (uint32_t)refStride;
-        k.ldsPerWave = (uint32_t)(4 * refStride);
-        b->pkLdsBytes = 4 * refStride * (DPX_FILL_THREADS / 64);
-        if (b->store && b->pkLdsBytes < kLdsFloor) b->pkLdsBytes = kLdsFloor; /* store-bound: 16 waves per CU (see above) */
-        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
-        if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
-        b->q16Args = k;
+    if (b->quad) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + four staged references */
+        const size_t refStride = align_up((size_t)b->maxN + 80, 16);
+        const size_t wpb = (size_t)dpx_quad_waves_per_block(kernelAlgo);
+        auto setup = [&](dpx_fill_args &k, int rows, size_t *ldsBytes) -> bool {
+            k = a;
+            k.ldsBufStride = (uint32_t)refStride;
+            k.ldsPerWave = (uint32_t)(dpx_quad_stage_bytes(kernelAlgo, rows, b->store) + 4 * refStride);
+            *ldsBytes = (size_t)k.ldsPerWave * wpb;
+            if (const char *env = getenv("DPX_LDS_PAD")) *ldsBytes += (size_t)std::max(0, atoi(env));
+            return *ldsBytes <= 160u * 1024u;
+        };
+        bool ok = setup(b->pkArgs, 8, &b->pkLdsBytes);
+        b->pkArgs.order = b->dCouples;
+        b->pkArgs.numPairs = (int32_t)numQuad8;
+        ok = setup(b->q16Args, 16, &b->q16LdsBytes) && ok;
         b->q16Args.order = b->dCouples + numQuad8;
         b->q16Args.numPairs = (int32_t)(couples.size() - numQuad8);
+        if (!ok) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+    }
+    if ((b->packed || b->quad) && (numSingles > 0 || (b->quad && numQuad8 > 0 && couples.size() > numQuad8))) {
+        /* more than one kernel per fill: a side stream + fork/join events (failure here only costs the overlap) */
+        if (stream_take(&b->sideStream) != hipSuccess) { b->sideStream = nullptr; (void)hipGetLastError(); }
+        if (b->sideStream && (hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&b->evJoin, hipEventDisableTiming) != hipSuccess)) (void)hipGetLastError();
     }
     b->nSingles = numSingles;
     b->nCouples = b->packed ? numCouples : 0;
@@ -785,19 +802,50 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     return DPX_OK;
 }
 
+/* One fill = up to three kernels over disjoint pairs (couples / quads of 8 and 16 rows per lane / leftover singles).  They do
+ * not depend on each other, but launches on one stream run one after the other -- and the small ones (the 4 % of a
+ * short-read batch with queries over 128 rows: 1000 waves on 1024 SIMDs) then cost a latency-bound tail of their own.
+ * The secondary kernels therefore go to the batch's side stream between a fork and a join event; on `s` the fill still
+ * looks like one operation (events recorded on `s` around it time all of it). */
 static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
-    if (b->packed) {
-        hipError_t e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+    const bool hasMain = b->args.numPairs > 0;
+    int kernels = 0;
+    if (b->packed) kernels++;
+    if (b->quad) kernels += (b->pkArgs.numPairs > 0) + (b->q16Args.numPairs > 0);
+    if (hasMain) kernels++;
+    hipStream_t side = s;
+    bool forked = false;
+    if (kernels > 1 && b->sideStream && b->evFork && b->evJoin) {
+        hipError_t e = hipEventRecord(b->evFork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(b->sideStream, b->evFork, 0);
         if (e != hipSuccess) return e;
+        side = b->sideStream;
+        forked = true;
     }
+    hipError_t e = hipSuccess;
+    /* secondary kernels first (they are the short ones; the main kernel then fills the chip around them) */
     if (b->quad) {
-        hipError_t e = dpx_launch_fill_quad(b->pkArgs, b->kernelAlgo, 8, b->store, b->pkLdsBytes, s);
-        if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->pkLdsBytes, s);
-        if (e != hipSuccess) return e;
-        if (b->args.numPairs == 0) return hipSuccess; /* no empty pairs left for the one-pair-per-wave kernel */
+        if (b->pkArgs.numPairs > 0) { /* main: 8 rows per lane; secondary: 16 rows per lane, then empties */
+            if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->q16LdsBytes, side);
+            if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
+            if (e == hipSuccess) e = dpx_launch_fill_quad(b->pkArgs, b->kernelAlgo, 8, b->store, b->pkLdsBytes, s);
+        } else {
+            if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
+            if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->q16LdsBytes, s);
+        }
+    } else if (b->packed) {
+        if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
+        if (e == hipSuccess) e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+    } else if (b->streamed) {
+        e = dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
+    } else {
+        e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
     }
-    if (b->streamed) return dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
-    hipError_t e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
+    if (forked) {
+        hipError_t j = hipEventRecord(b->evJoin, side);
+        if (j == hipSuccess) j = hipStreamWaitEvent(s, b->evJoin, 0);
+        if (e == hipSuccess) e = j;
+    }
     return e;
 }
 

@@ -38,6 +38,9 @@ typedef struct dpx_fill_args {
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
+/* LDS of the quad kernels' line stage per wave (0 when score-only), and waves per workgroup of the kernel for `algo` */
+size_t dpx_quad_stage_bytes(int algo, int R, bool store);
+int dpx_quad_waves_per_block(int algo);
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,

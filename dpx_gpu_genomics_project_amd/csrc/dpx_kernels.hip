@@ -47,6 +47,53 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DPX_EXP_NORAMPSTORE
 #define DPX_EXP_NORAMPSTORE 0
 #endif
+/* ablation builds of the quad kernels (tools/ab_quad.sh): 1 = no global stores, 2 = stores without the LDS round trip */
+#ifndef DPX_EXP_QUAD
+#define DPX_EXP_QUAD 0
+#endif
+
+/* ---- sequence staging: wide loads instead of one byte per lane and instruction ----------------------------------
+ * Sequences sit at arbitrary byte offsets of the flat parseInput buffer (c++/parseInput.cpp:78-112 keeps the file's
+ * bytes where they are).  stage_bytes() copies a string into LDS with aligned 16-byte loads and stores: the copy
+ * starts at the 16-byte block that holds the first character, so the string lands `src & 15` bytes into the
+ * (16-byte aligned) LDS buffer; the returned pointer is its first character.  The buffer needs n + 31 bytes.  The
+ * device arena is 256-byte aligned and padded, so the blocks read never leave it.  `l` = the calling lane's index
+ * among the G lanes that share the copy. */
+__device__ __forceinline__ unsigned char *stage_bytes(unsigned char *dst16, const unsigned char *src, const int n, const int l, const int G) {
+    const unsigned a = (unsigned)(reinterpret_cast<uintptr_t>(src) & 15u);
+    const u32x4 *from = reinterpret_cast<const u32x4 *>(src - a);
+    u32x4 *to = reinterpret_cast<u32x4 *>(dst16);
+    const int blocks = (int)((a + (unsigned)n + 15u) >> 4);
+    for (int k = l; k < blocks; k += G) to[k] = from[k];
+    return dst16 + a;
+}
+
+/* the R query characters of a lane's rows (row0 .. row0+R-1 of `qry`) from R/4 + 1 aligned dword loads and
+ * v_alignbyte_b32 instead of R byte loads; rows past the query's end get 0x100 (matches no byte) */
+template <int R>
+__device__ __forceinline__ void load_query_rows(int (&qc)[R], const unsigned char *qry, const int row0, const int nrows) {
+    if (nrows <= 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) qc[r] = 0x100;
+        return;
+    }
+    constexpr int W = (R + 3) / 4;
+    const unsigned char *at = qry + row0;
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(at) & 3u);
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(at - sh);
+    uint32_t d[W + 1];
+#pragma unroll
+    for (int k = 0; k <= W; k++) d[k] = al[k];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const uint32_t v = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh); /* bytes 4k .. 4k+3 of the lane's rows */
+#pragma unroll
+        for (int bq = 0; bq < 4 && 4 * k + bq < R; bq++) {
+            const int r = 4 * k + bq;
+            qc[r] = (r < nrows) ? (int)((v >> (8 * bq)) & 0xFFu) : 0x100;
+        }
+    }
+}
 
 template <class V>
 __device__ __forceinline__ void stream_store(V *dst, V v) {
@@ -390,19 +437,76 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
 }
 
 /* =====================================================================================================
- * Quad kernel for short queries (the reference's own dataset shape: reads of 80-150 bases, cuda/LNW V12 on
+ * Quad kernels for short queries (the reference's own dataset shape: reads of 80-150 bases, cuda/LNW V12 on
  * bsw/small): FOUR pairs per wave, one per 16-lane DPP row.  Lane l of a row owns rows [l*R, l*R+R) of its pair (16*R
  * rows: 128 at R = 8, 256 at R = 16), `up` moves with `v_mov_b32_dpp row_shr:1` (lanes 0/16/32/48 have no source and
  * keep the row-0 border), so the skew ramp is 15 steps instead of 63 and a 100-row query keeps 13 of 16 lanes busy
  * instead of 13 (or 25) of 64.  The four pairs may differ in shape: n, m, pointers are per-lane values, the wave runs
- * max(n)+15 steps and every row masks itself.  Each row stores its own 16*R*2-byte chunk per step; the host places
- * the four pairs of a wave next to each other so the wave's store covers one contiguous 4-chunk block.
+ * max(n)+15 steps and every row masks itself.
+ *
+ * Writeback: 8 x 8 tile layout (dpx_layout.h), one whole 128-byte line per (row block, column block), through an LDS
+ * transpose.  Per step a lane parks its 8 (16) new scores -- 16 B per row block -- in its own LDS line (ds_write_b128);
+ * a lane's line is complete when its column index reaches a multiple of 8, which happens for the lanes
+ * lambda = (t+1) mod 8 of every 8-lane group in step t: eight lines, read back so that lane x of the wave holds piece
+ * x%8 of the line of lane 8*(x/8) + (t+1)%8 (ds_read_b128) and written by ONE global_store_dwordx4 of eight whole
+ * lines.  Every stored byte is a cell (or the < 8-column tail of a pair's last column block): no skew-ramp padding, rows
+ * rounded up to 8 instead of 64/128 -- round 1's [step][lane][rows] chunks wrote 1.40x the algorithmic bytes on short
+ * reads.  LDS lines are 144 bytes apart and column c of lane lambda's line sits in slot (c + lambda) % 8 -- which is
+ * t % 8 for every lane of the wave in step t, the skew cancels: conflict-free for the b128 write groups (8 contiguous
+ * lanes, banks 4*lambda + const) and for the b128 read groups of MI355X_MICROARCH.md (4 x 16 lanes).  The store of the lines read in step t is issued in step
+ * t+1, behind that step's arithmetic.
  * ===================================================================================================== */
 __device__ __forceinline__ int row_shr1(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x111, 0xf, 0xf, false); }
+
+constexpr int kStageLine = 144; /* bytes between two LDS lines */
+template <int Q, int PLANES>
+struct LineStage {
+    static constexpr int kBytes = PLANES * Q * 64 * kStageLine; /* per wave */
+    u32x4 pend[PLANES * Q];
+    int16_t *pendDst = nullptr; /* line of (plane 0, sub-tile 0); plane p, sub-tile h: + (p*LB + h)*64 elements */
+    int pendN = 0;              /* sub-tiles of the owner lane that hold rows (0: nothing to store) */
+
+    /* park the lane's 8 rows of sub-tile h, plane p, in slot t % 8 of its line (t = the wave's step) */
+    static __device__ __forceinline__ void put(unsigned char *tile, int lane, int p, int h, int t, u32x4 v) {
+#if DPX_EXP_QUAD == 2
+        if (t == -5)
+#endif
+        *reinterpret_cast<u32x4 *>(tile + ((p * Q + h) * 64 + lane) * kStageLine + ((t & 7) << 4)) = v;
+    }
+    /* write out what fetch() read one step ago */
+    __device__ __forceinline__ void store(const uint32_t LB) {
+#if DPX_EXP_QUAD == 1
+        if (pendN == 77) /* never */
+#endif
+#pragma unroll
+        for (int h = 0; h < Q; h++) {
+            if (h < pendN) {
+#pragma unroll
+                for (int p = 0; p < PLANES; p++) stream_store(reinterpret_cast<u32x4 *>(pendDst + ((size_t)(p * LB + h) << 6)), pend[p * Q + h]);
+            }
+        }
+    }
+    /* read piece lane%8 of the lines of lane `owner` (wave lane number) */
+    __device__ __forceinline__ void fetch(const unsigned char *tile, int lane, int owner, int nValid, int16_t *dst) {
+#pragma unroll
+        for (int p = 0; p < PLANES; p++)
+#pragma unroll
+            for (int h = 0; h < Q; h++)
+#if DPX_EXP_QUAD == 2
+                pend[p * Q + h].x += (uint32_t)owner;
+#else
+                pend[p * Q + h] = *reinterpret_cast<const u32x4 *>(tile + ((p * Q + h) * 64 + owner) * kStageLine + (((lane + owner) & 7) << 4));
+#endif
+        pendN = nValid;
+        pendDst = dst;
+    }
+};
 
 template <int R, bool LOCAL, bool STORE>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Q = R / 8;
+    using Stage = LineStage<Q, 1>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
@@ -417,15 +521,16 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
-    unsigned char *refl = smem + (size_t)wv * a.ldsPerWave + (size_t)q * a.ldsBufStride; /* this row's reference: [16 + (j-1)] */
-    for (int x = l; x < n; x += 16) refl[16 + x] = ref[x];
+    unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;                       /* the wave's line stage */
+    unsigned char *refl = tileL + (STORE ? Stage::kBytes : 0) + (size_t)q * a.ldsBufStride; /* this row's reference: [16 + (j-1)] */
+    const unsigned char *refs = stage_bytes(refl + 16, ref, n, l, 16);
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
     LinState<R, LOCAL> st;
+    load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
         st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
         st.key[r] = 0u;
     }
@@ -433,33 +538,37 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
 
     const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
                          max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
-    const int storeLanes = min(16, ((m + R - 1) / R + 7) & ~7); /* whole 128-byte lines (8 lanes x 16 B), see store_lanes */
-    int16_t *tile = a.mat + pr.matOff + (size_t)l * (R < 8 ? R : 8);
-    const size_t cs = pr.chunkStride;
-    const unsigned char *rp = refl + 16 - l; /* rp[t] = reference character of column j = t - l + 1 */
+    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
+    int16_t *matp = a.mat + pr.matOff + ((size_t)(lane & 7) << 3); /* this lane's 16-byte piece of a line */
+    const int n8 = (n + 7) & ~7;
+    const unsigned char *rp = refs - l; /* rp[t] = reference character of column j = t - l + 1 */
     int rcN = rp[0];
-    const int steps = nmax + 15;
+    Stage stage;
+    const int steps = (STORE ? ((nmax + 7) & ~7) : nmax) + 15;
     auto quad_step = [&](const int t) {
         const int j = t - l + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
         const int upin = row_shr1(st.Hl[R - 1], LOCAL ? 0 : (t + 1) * gap); /* lanes 0/16/32/48: row-0 border of column t+1 */
-        if (has && nrows > 0 && j >= 1 && j <= n) lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
+        const bool active = has && nrows > 0 && j >= 1 && j <= n;
+        if (active) lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
         if constexpr (STORE) {
-            if (has && t < n + 15 && l < storeLanes) { /* whole chunks of this row's pair while it is running */
+            if (active) {
                 uint32_t wd[(R + 1) / 2];
                 lin_pack<R, LOCAL>(st, wd);
-                int16_t *dst = tile + (size_t)t * cs;
-                if constexpr (R <= 4) {
-                    store_words<R>(dst, wd);
-                } else {
 #pragma unroll
-                    for (int h = 0; h < R / 8; h++) {
-                        u32x4 v = {wd[4 * h + 0], wd[4 * h + 1], wd[4 * h + 2], wd[4 * h + 3]};
-                        stream_store(reinterpret_cast<u32x4 *>(dst + h * 128), v); /* sub-tile h: [16 lanes][8] */
-                    }
+                for (int h = 0; h < Q; h++) {
+                    u32x4 v = {wd[4 * h + 0], wd[4 * h + 1], wd[4 * h + 2], wd[4 * h + 3]};
+                    Stage::put(tileL, lane, 0, h, t, v);
                 }
             }
+            stage.store(LB);
+            /* the lanes (t+1)%8 of every 8-lane group have just finished a column block (or ran past the pair's last,
+             * partial one): this lane fetches piece lane%8 of its group's line */
+            const int lg = (l & 8) | ((t + 1) & 7); /* owner's lane inside the pair */
+            const int jg = t - lg + 1;              /* owner's column: a multiple of 8 */
+            const int nValid = (has && jg >= 8 && jg <= n8) ? min(max((int)LB - lg * Q, 0), Q) : 0; /* row blocks of the owner that exist */
+            stage.fetch(tileL, lane, (lane & ~7) | ((t + 1) & 7), nValid, matp + (size_t)((jg >> 3) - 1) * cs + ((size_t)(lg * Q) << 6));
         }
     };
     {
@@ -470,6 +579,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
         }
         if (t < steps) quad_step(t);
     }
+    if constexpr (STORE) stage.store(LB);
     if (!has) return;
     if constexpr (LOCAL) {
         int bestv = 0, bestrow = 0, bestcol = 0;
@@ -1113,13 +1223,18 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
 }
 
 /* Affine quad kernel: the Gotoh recurrence of k_affine_fill on the four-pairs-per-wave schedule of k_linear_quad
- * (16 lanes per pair, `up` of H and D through row_shr:1, three planes [H][I][D] of [16 lanes][8] sub-tiles per step). */
+ * (16 lanes per pair, `up` of H and D through row_shr:1); the three planes H, I, D leave through the same LDS line
+ * stage into the 8 x 8 tile layout, three whole-line stores per step.  One wave per workgroup: the stage needs
+ * 27 KiB of LDS per wave (three planes), so small workgroups keep five of them on a CU. */
+#define DPX_AQUAD_THREADS 64
 template <int R, bool STORE>
-__global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill_args a) {
+__global__ void __launch_bounds__(DPX_AQUAD_THREADS) k_affine_quad(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Q = R / 8;
+    using Stage = LineStage<Q, 3>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    const int w = blockIdx.x * (DPX_AQUAD_THREADS / 64) + wv;
     if (4 * w >= a.numPairs) return; /* wave-uniform */
     const int q = lane >> 4, l = lane & 15;
     const int slot = 4 * w + q;
@@ -1132,15 +1247,16 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
-    unsigned char *refl = smem + (size_t)wv * a.ldsPerWave + (size_t)q * a.ldsBufStride;
-    for (int x = l; x < n; x += 16) refl[16 + x] = ref[x];
+    unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;
+    unsigned char *refl = tileL + (STORE ? Stage::kBytes : 0) + (size_t)q * a.ldsBufStride;
+    const unsigned char *refs = stage_bytes(refl + 16, ref, n, l, 16);
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
     AffState<R> st;
+    load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
         st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (AffineNeedlemanWunsch.cpp:43-46) */
         st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
         st.Dl[r] = DPX_NEG;
@@ -1149,36 +1265,39 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill
 
     const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
                          max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
-    const int storeLanes = min(16, ((m + R - 1) / R + 7) & ~7); /* whole 128-byte lines (8 lanes x 16 B), see store_lanes */
-    int16_t *tile = a.mat + pr.matOff + (size_t)l * 8;
-    const size_t cs = pr.chunkStride;
-    const unsigned char *rp = refl + 16 - l;
+    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
+    int16_t *matp = a.mat + pr.matOff + ((size_t)(lane & 7) << 3);
+    const int n8 = (n + 7) & ~7;
+    const unsigned char *rp = refs - l;
     int rcN = rp[0];
-    const int steps = nmax + 15;
+    Stage stage;
+    const int steps = (STORE ? ((nmax + 7) & ~7) : nmax) + 15;
+    auto pack8 = [](const int *v) -> u32x4 {
+        u32x4 w = {pack_lo16(v[0], v[1]), pack_lo16(v[2], v[3]), pack_lo16(v[4], v[5]), pack_lo16(v[6], v[7])};
+        return w;
+    };
     auto quad_step = [&](const int t) {
         const int j = t - l + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
         const int upH = row_shr1(st.Hl[R - 1], o + (t + 1) * e); /* row-0 border H[0][j] = o + j*e (:50-53) */
         const int upD = row_shr1(st.Dl[R - 1], DPX_NEG);         /* virtual D[0][j] */
-        if (has && nrows > 0 && j >= 1 && j <= n) aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
+        const bool active = has && nrows > 0 && j >= 1 && j <= n;
+        if (active) aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
         if constexpr (STORE) {
-            if (has && t < n + 15 && l < storeLanes) {
-                int16_t *dst = tile + (size_t)t * cs;
+            if (active) {
 #pragma unroll
-                for (int h = 0; h < R / 8; h++) {
-                    u32x4 vh = {pack_lo16(st.Hl[8 * h + 0], st.Hl[8 * h + 1]), pack_lo16(st.Hl[8 * h + 2], st.Hl[8 * h + 3]),
-                                pack_lo16(st.Hl[8 * h + 4], st.Hl[8 * h + 5]), pack_lo16(st.Hl[8 * h + 6], st.Hl[8 * h + 7])};
-                    u32x4 vi = {pack_lo16(st.Il[8 * h + 0], st.Il[8 * h + 1]), pack_lo16(st.Il[8 * h + 2], st.Il[8 * h + 3]),
-                                pack_lo16(st.Il[8 * h + 4], st.Il[8 * h + 5]), pack_lo16(st.Il[8 * h + 6], st.Il[8 * h + 7])};
-                    u32x4 vd = {pack_lo16(st.Dl[8 * h + 0], st.Dl[8 * h + 1]), pack_lo16(st.Dl[8 * h + 2], st.Dl[8 * h + 3]),
-                                pack_lo16(st.Dl[8 * h + 4], st.Dl[8 * h + 5]), pack_lo16(st.Dl[8 * h + 6], st.Dl[8 * h + 7])};
-                    constexpr int Q = R / 8;
-                    stream_store(reinterpret_cast<u32x4 *>(dst + (0 * Q + h) * 128), vh);
-                    stream_store(reinterpret_cast<u32x4 *>(dst + (1 * Q + h) * 128), vi);
-                    stream_store(reinterpret_cast<u32x4 *>(dst + (2 * Q + h) * 128), vd);
+                for (int h = 0; h < Q; h++) {
+                    Stage::put(tileL, lane, 0, h, t, pack8(&st.Hl[8 * h]));
+                    Stage::put(tileL, lane, 1, h, t, pack8(&st.Il[8 * h]));
+                    Stage::put(tileL, lane, 2, h, t, pack8(&st.Dl[8 * h]));
                 }
             }
+            stage.store(LB);
+            const int lg = (l & 8) | ((t + 1) & 7);
+            const int jg = t - lg + 1;
+            const int nValid = (has && jg >= 8 && jg <= n8) ? min(max((int)LB - lg * Q, 0), Q) : 0; /* row blocks of the owner that exist */
+            stage.fetch(tileL, lane, (lane & ~7) | ((t + 1) & 7), nValid, matp + (size_t)((jg >> 3) - 1) * cs + ((size_t)(lg * Q) << 6));
         }
     };
     {
@@ -1189,6 +1308,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_quad(const dpx_fill
         }
         if (t < steps) quad_step(t);
     }
+    if constexpr (STORE) stage.store(LB);
     if (!has) return;
     const int lm = (m - 1) / R, rm = (m - 1) % R;
     if (l == lm) {
@@ -1399,7 +1519,7 @@ __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, i
             const int dlt = i - j;
             v = (dlt <= band - 1 && -dlt <= band - 1) ? mat[pr.matOff + dpx_band_index(i, j, band, pr.chunkStride)] : 0;
         } else {
-            v = mat[pr.matOff + dpx_tiled_index(i, j, n, R, plane, pr.chunkStride, pr.lanes)];
+            v = mat[pr.matOff + dpx_cell_index(i, j, n, R, plane, planes, pr.chunkStride, pr.lanes)];
         }
         out[idx] = (int16_t)v;
     }
@@ -1433,7 +1553,7 @@ struct TbView {
             if (dlt > band - 1 || -dlt > band - 1) return 0;
             return mat[off + dpx_band_index(i, j, band, cs)];
         }
-        return mat[off + dpx_tiled_index(i, j, n, R, plane, cs, lanes)];
+        return mat[off + dpx_cell_index(i, j, n, R, plane, planes, cs, lanes)];
     }
 };
 
@@ -1466,10 +1586,9 @@ struct TileWalker {
     __device__ __forceinline__ u32x4 column(int i0, int jj) const { /* the 8-row group of row i0 (0-based), column jj >= 1 */
         const int r = i0 & ((1 << sr) - 1), sub = r >> 3;
         uint64_t T, tile;
-        if (lanes == 16) {
-            const int l = i0 >> sr;
-            T = (uint64_t)((jj - 1) + l);
-            tile = (uint64_t)(((sub << 4) + l) << 3);
+        if (lanes == 16) { /* 8 x 8 tile layout: the column's 8 rows are one 16-byte piece of the row block's line */
+            T = (uint64_t)((jj - 1) >> 3);
+            tile = (uint64_t)(((i0 >> 3) << 6) + (((jj - 1) & 7) << 3));
         } else {
             const int k = i0 >> (sr + 6), l = (i0 >> sr) & 63;
             T = (uint64_t)k * (uint64_t)n + (uint64_t)(jj - 1) + (uint64_t)l;
@@ -1489,7 +1608,7 @@ struct TileWalker {
     /* a single cell outside the two cached columns' 8-row group (the row above the group): plain 2-byte load */
     __device__ __forceinline__ int single(int ii, int jj) const {
         if (ii == 0 || jj == 0) return border * (ii + jj);
-        return mat[off + dpx_tiled_index(ii, jj, n, 1 << sr, 0, cs, lanes)];
+        return mat[off + dpx_cell_index(ii, jj, n, 1 << sr, 0, 1, cs, lanes)];
     }
     __device__ __forceinline__ int here() const { return (i == 0 || j == 0) ? border * (i + j) : elem(cur, (i - 1) & 7); }
     __device__ __forceinline__ int up() const {
@@ -1776,25 +1895,44 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
     return hipErrorInvalidValue;
 }
 
-/* quad kernel (short queries): a.order = pair slots, 4 per wave; a.numPairs = number of slots */
+/* quad kernels (short queries): a.order = pair slots, 4 per wave; a.numPairs = number of slots.  ldsBytes is per
+ * workgroup: dpx_quad_lds_per_wave() x waves per workgroup (4 for the linear kernels, 1 for the affine one). */
+size_t dpx_quad_stage_bytes(int algo, int R, bool store) {
+    if (!store) return 0;
+    return (size_t)(algo == DPX_K_ANW ? 3 : 1) * (size_t)(R / 8) * 64u * (size_t)kStageLine;
+}
+int dpx_quad_waves_per_block(int algo) { return algo == DPX_K_ANW ? DPX_AQUAD_THREADS / 64 : DPX_FILL_THREADS / 64; }
+
+template <class K>
+static hipError_t launch_quad_kernel(K kernel, const dpx_fill_args &a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+    if (lds > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int pairsPerBlock = 4 * (DPX_FILL_THREADS / 64);
+    const int pairsPerBlock = 4 * dpx_quad_waves_per_block(algo);
     dim3 grid((unsigned)((a.numPairs + pairsPerBlock - 1) / pairsPerBlock));
     if (algo == DPX_K_ANW) {
-        if (R == 8) return store ? launch_fill_kernel(k_affine_quad<8, true>, a, grid, ldsBytes, stream)
-                                 : launch_fill_kernel(k_affine_quad<8, false>, a, grid, ldsBytes, stream);
-        if (R == 16) return store ? launch_fill_kernel(k_affine_quad<16, true>, a, grid, ldsBytes, stream)
-                                  : launch_fill_kernel(k_affine_quad<16, false>, a, grid, ldsBytes, stream);
+        const int th = DPX_AQUAD_THREADS;
+        if (R == 8) return store ? launch_quad_kernel(k_affine_quad<8, true>, a, grid, th, ldsBytes, stream)
+                                 : launch_quad_kernel(k_affine_quad<8, false>, a, grid, th, ldsBytes, stream);
+        if (R == 16) return store ? launch_quad_kernel(k_affine_quad<16, true>, a, grid, th, ldsBytes, stream)
+                                  : launch_quad_kernel(k_affine_quad<16, false>, a, grid, th, ldsBytes, stream);
         return hipErrorInvalidValue;
     }
     const bool local = algo == DPX_K_LSW;
-#define DPX_QUAD_CASE(R_)                                                                                          \
-    case R_:                                                                                                      \
-        if (local) return store ? launch_fill_kernel(k_linear_quad<R_, true, true>, a, grid, ldsBytes, stream)    \
-                                : launch_fill_kernel(k_linear_quad<R_, true, false>, a, grid, ldsBytes, stream);  \
-        return store ? launch_fill_kernel(k_linear_quad<R_, false, true>, a, grid, ldsBytes, stream)              \
-                     : launch_fill_kernel(k_linear_quad<R_, false, false>, a, grid, ldsBytes, stream);
+    const int th = DPX_FILL_THREADS;
+#define DPX_QUAD_CASE(R_)                                                                                              \
+    case R_:                                                                                                          \
+        if (local) return store ? launch_quad_kernel(k_linear_quad<R_, true, true>, a, grid, th, ldsBytes, stream)    \
+                                : launch_quad_kernel(k_linear_quad<R_, true, false>, a, grid, th, ldsBytes, stream);  \
+        return store ? launch_quad_kernel(k_linear_quad<R_, false, true>, a, grid, th, ldsBytes, stream)              \
+                     : launch_quad_kernel(k_linear_quad<R_, false, false>, a, grid, th, ldsBytes, stream);
     switch (R) {
         DPX_QUAD_CASE(8)
         DPX_QUAD_CASE(16)

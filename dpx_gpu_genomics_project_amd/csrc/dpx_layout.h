@@ -47,7 +47,7 @@ typedef struct dpx_pair_dev {
     int32_t qryIdx, m;  /* query offset / length      (rows)    */
     uint64_t matOff;    /* first int16 element of this pair's chunk 0 */
     uint32_t chunkStride; /* int16 elements between consecutive chunks (steps) of this pair */
-    uint16_t lanes;       /* lanes that own this pair's rows: 64 (one wave per pair) or 16 (quad kernel: 4 pairs per wave) */
+    uint16_t lanes;       /* 64: wavefront-tiled layout (one wave per pair); 16: 8x8-tile layout (quad kernels, 4 pairs per wave) */
     uint16_t rows;        /* rows per lane of the kernel that fills this pair (quad batches mix 8 and 16); 0 = the batch's */
 } dpx_pair_dev;
 
@@ -68,25 +68,37 @@ DPX_HD uint32_t dpx_tile_off(int R, int plane, int l, int r) {
     const int sq = R < 8 ? dpx_log2(R) : 3, Q = R >> sq; /* sub-tiles of 2^sq rows */
     return (uint32_t)(((((plane * Q + (r >> sq)) << 6) + l) << sq) + (r & ((1 << sq) - 1)));
 }
-/* Quad layout (short queries, 4 pairs per wave): a pair's rows belong to 16 lanes, l = (i-1)/R, single stripe of 16*R
- * rows, chunk T = (j-1) + l holds [plane][sub-tile][16 lanes][<=8 rows]; n + 15 chunks per pair. */
-DPX_HD uint64_t dpx_quad_chunks(int m, int n) { return (m <= 0 || n <= 0) ? 0 : (uint64_t)n + 15u; }
-DPX_HD uint32_t dpx_quad_tile_off(int R, int plane, int l, int r) {
-    const int sq = R < 8 ? dpx_log2(R) : 3, Q = R >> sq;
-    return (uint32_t)(((((plane * Q + (r >> sq)) << 4) + l) << sq) + (r & ((1 << sq) - 1)));
+/* Tile layout (pairs filled by the quad kernels, dpx_pair_dev.lanes == 16): the matrix is cut into 8 x 8 tiles, one
+ * 128-byte line each, column-block-major, columns before rows inside the tile:
+ *
+ *       element(i, j, plane) = matOff + cb*chunkStride + (plane*LB + rb)*64 + c*8 + rr
+ *       with rb = (i-1)/8, rr = (i-1)%8, cb = (j-1)/8, c = (j-1)%8, LB = ceil(m/8), chunkStride = planes*LB*64
+ *
+ * so the 8 rows of one column inside a row block are 16 contiguous bytes (what a lane produces per step) and the 8
+ * columns of a row block are one whole line (what a lane has produced after 8 steps).  Nothing depends on the wave's
+ * skew: ceil(n/8) * ceil(m/8) lines per plane and pair, no ramp padding, rows rounded up to 8 instead of to the 64-row
+ * height of a [lane][8 rows] line (a 104 x 130 pair: 28.3 KB stored for 27.5 KB algorithmic; the [step][lane][rows]
+ * chunks of round 1 stored 37 KB).  The kernels transpose through LDS to get there, see k_linear_quad. */
+DPX_HD uint32_t dpx_tile8_row_blocks(int m) { return (uint32_t)((m + 7) >> 3); }
+DPX_HD uint64_t dpx_tile8_col_blocks(int m, int n) { return (m <= 0 || n <= 0) ? 0 : (uint64_t)((n + 7) >> 3); }
+DPX_HD uint32_t dpx_tile8_chunk_elems(int m, int planes) { return (uint32_t)planes * dpx_tile8_row_blocks(m) * 64u; }
+DPX_HD uint64_t dpx_tile8_index(int i, int j, int plane, int planes, uint32_t chunkStride) {
+    const uint32_t LB = chunkStride / (64u * (uint32_t)planes);
+    const int i0 = i - 1, j0 = j - 1;
+    return (uint64_t)(j0 >> 3) * (uint64_t)chunkStride + (uint64_t)((((uint32_t)plane * LB + (uint32_t)(i0 >> 3)) << 6) + ((j0 & 7) << 3) + (i0 & 7));
 }
 /* offset of cell (i, j) of `plane` relative to the pair's matOff */
-DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride, uint32_t lanes = 64) {
+DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride) {
     const int sr = dpx_log2(R), i0 = i - 1;
-    if (lanes == 16) {
-        const int l = i0 >> sr, r = i0 & (R - 1);
-        return (uint64_t)((j - 1) + l) * (uint64_t)chunkStride + (uint64_t)dpx_quad_tile_off(R, plane, l, r);
-    }
     const int k = i0 >> (sr + 6);
     const int l = (i0 >> sr) & 63;
     const int r = i0 & (R - 1);
     uint64_t T = (uint64_t)k * (uint64_t)n + (uint64_t)(j - 1) + (uint64_t)l;
     return T * (uint64_t)chunkStride + (uint64_t)dpx_tile_off(R, plane, l, r);
+}
+/* either layout, by the pair's `lanes` tag */
+DPX_HD uint64_t dpx_cell_index(int i, int j, int n, int R, int plane, int planes, uint32_t chunkStride, uint32_t lanes) {
+    return lanes == 16 ? dpx_tile8_index(i, j, plane, planes, chunkStride) : dpx_tiled_index(i, j, n, R, plane, chunkStride);
 }
 
 /*
