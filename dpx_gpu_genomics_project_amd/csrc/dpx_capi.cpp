@@ -237,12 +237,11 @@ struct dpx_batch {
     bool streamed = false; /* uniform batch on the stream schedule (k_linear_stream) */
     size_t streamLds = 0;
     bool packed = false;
-    bool quad = false;     /* short queries: four pairs per wave (k_linear_quad); slots in dCouples: first the pairs of
-                              <= 128 rows (8 rows per lane, pkArgs), then those of <= 256 (16 rows per lane, q16Args) */
-    dpx_fill_args q16Args{};
+    bool quad = false;     /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
+                              descriptors in dCouples, launch arguments in pkArgs */
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
-    size_t pkLdsBytes = 0, q16LdsBytes = 0;
+    size_t pkLdsBytes = 0;
     /* traceback (lazy): device line buffers + host mirror */
     uint64_t *dTbOff = nullptr;
     char *dTb = nullptr;
@@ -253,7 +252,7 @@ struct dpx_batch {
     size_t dTbCap = 0, hTbCap = 0; /* capacities of the (possibly recycled) buffers */
     std::vector<int32_t> hTbLen;
     bool tbValid = false;
-    size_t nSingles = 0, nCouples = 0, nQuad8 = 0, nQuad16 = 0; /* launch-list sizes (dpx_batch_describe) */
+    size_t nSingles = 0, nCouples = 0, nLanePairs = 0, nWaves = 0; /* launch-list sizes (dpx_batch_describe) */
 };
 
 extern "C" {
@@ -371,6 +370,58 @@ static bool packed_safe(const dpx_params &p, long long m, long long n) {
     const long long hi = diag + pos(p.gapOpen) * (m + n);
     const long long lo = p.algo == DPX_ALGO_LNW ? neg(p.gapOpen) * (m + n) : 0;
     return lo + wmin >= -32768 && hi + wmax <= 32767 && n <= 65535;
+}
+
+/* rows per lane of the lane-packed kernels: a pair of m rows takes ceil(m / 8) lanes (m <= 512); 16 rows per lane (two row
+ * blocks) for the linear-gap kernels up to 1024 rows */
+static int lanes_rows(int maxM, int algo) { return (maxM <= 512 || algo == DPX_ALGO_ANW) ? 8 : 16; }
+
+/* Pack pairs (`idx`, sorted by reference length, longest first) into waves of 64 lanes for the lane-packed kernels:
+ * a pair takes ceil(m / R) consecutive lanes, a wave up to DPX_WAVE_SLOTS pairs whose staged references fit the wave's
+ * LDS reference area.  Best fit over a window of open waves, so that the pairs of a wave have nearly the same reference
+ * length (the wave runs max(n + lanes) steps) and the lanes fill up: 100k short reads (queries 80-130) reach 94 % lane
+ * occupancy.  Returns the reference area in bytes; `idx` comes back in slot order (= matrix placement order). */
+static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int32_t> &idx, int R, int maxN, std::vector<dpx_wave_desc> &waves) {
+    struct Bin { dpx_wave_desc d; int lanes = 0, slots = 0; size_t ref = 0; };
+    const size_t refCap = std::max<size_t>(1024, align_up((size_t)maxN + 31, 16));
+    constexpr size_t kWindow = 256;
+    std::vector<Bin> open;
+    std::vector<int32_t> order;
+    order.reserve(idx.size());
+    size_t area = 0;
+    auto emit = [&](const Bin &bn) {
+        waves.push_back(bn.d);
+        for (int k = 0; k < bn.slots; k++) order.push_back(bn.d.pair[k]);
+        area = std::max(area, bn.ref);
+    };
+    for (int32_t i : idx) {
+        const dpx_pair_dev &pd = pairs[i];
+        const int L = (pd.m + R - 1) / R;
+        const size_t need = align_up((size_t)pd.n + 31, 16);
+        int best = -1;
+        for (size_t k = 0; k < open.size(); k++) {
+            const Bin &bn = open[k];
+            if (bn.lanes + L > 64 || bn.slots >= DPX_WAVE_SLOTS || bn.ref + need > refCap) continue;
+            if (best < 0 || bn.lanes > open[best].lanes) best = (int)k; /* tightest fit */
+        }
+        if (best < 0) {
+            if (open.size() >= kWindow) { emit(open.front()); open.erase(open.begin()); }
+            open.emplace_back();
+            memset(&open.back().d, 0, sizeof(dpx_wave_desc));
+            best = (int)open.size() - 1;
+        }
+        Bin &bn = open[best];
+        bn.d.pair[bn.slots] = i;
+        bn.d.first[bn.slots] = (uint8_t)bn.lanes;
+        bn.d.num[bn.slots] = (uint8_t)L;
+        bn.d.refOff[bn.slots] = (uint16_t)(bn.ref >> 4);
+        bn.lanes += L;
+        bn.slots++;
+        bn.ref += need;
+    }
+    for (const Bin &bn : open) emit(bn);
+    idx.swap(order);
+    return area;
 }
 
 /* cells (i, j) with 1 <= i <= m, 1 <= j <= n, |i - j| <= B - 1: sum over the rows of min(n, i+B-1) - max(1, i-B+1) + 1 */
@@ -505,75 +556,41 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (e__ != hipSuccess) { int r__ = hip_fail(e__, #call); dpx_batch_destroy(b); return r__; } \
     } while (0)
 
-    trace.mark("create: validate+geometry");
-    CREATE_TRY(stream_take(&b->stream));
-    trace.mark("create: stream");
-    int32_t *arenaOrder = nullptr, *arenaCouples = nullptr;
-    /* only the bytes this batch's pairs touch go to the device (a driver that cuts one big file into batches hands the
-     * whole file to every dpx_batch_create): upload [seqLo, seqHi) and rebase the device-side indices */
-    size_t seqLo = numBytes, seqHi = 0;
-    for (size_t i = 0; i < numPairs; i++) {
-        const dpx_pair_dev &pd = b->pairs[i];
-        seqLo = std::min(seqLo, (size_t)std::min(pd.refIdx, pd.qryIdx));
-        seqHi = std::max(seqHi, std::max((size_t)pd.refIdx + (size_t)pd.n, (size_t)pd.qryIdx + (size_t)pd.m));
-    }
-    if (seqHi <= seqLo) seqLo = seqHi = 0;
-    for (size_t i = 0; i < numPairs; i++) { b->pairs[i].refIdx -= (int32_t)seqLo; b->pairs[i].qryIdx -= (int32_t)seqLo; }
-    sequences += seqLo;
-    numBytes = seqHi - seqLo;
-    {
-        const size_t np1 = std::max<size_t>(numPairs, 1);
-        const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
-        const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
-        const size_t need = szSeq + szPairs + 6 * szI32 + szOff; /* score, endRow, endCol, order, couples, tbLen */
-        CREATE_TRY(g_arenaCache.take((void **)&b->arena, need, &b->arenaCap));
-        char *q = b->arena;
-        b->dSeq = q;                  q += szSeq;
-        b->dPairs = (dpx_pair_dev *)q; q += szPairs;
-        b->dScore = (int32_t *)q;     q += szI32;
-        b->dEndRow = (int32_t *)q;    q += szI32;
-        b->dEndCol = (int32_t *)q;    q += szI32;
-        b->dOrder = nullptr;          arenaOrder = (int32_t *)q; q += szI32;
-        b->dCouples = nullptr;        arenaCouples = (int32_t *)q; q += szI32;
-        b->dTbLen = (int32_t *)q;     q += szI32;
-        b->dTbOff = (uint64_t *)q;
-    }
-    trace.mark("create: arena");
-    if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
-    trace.mark("create: H2D sequences");
     /* launch lists.  Packed path: couple pairs of identical (m, n); everything else runs one pair per wave, longest first. */
     std::vector<int32_t> singles, couples;
-    size_t numQuad8 = 0;
     /* "+Opt" packed path (two equal-shaped pairs per wave on the v_pk_*_i16 pipe).  The fill is bound by store
      * instructions per CU-cycle, so halving the VALU work buys no cycles -- it buys clock: the chip holds ~2.3 GHz
      * instead of ~2.1 GHz under the lighter instruction stream (profiles/README.md), 4-7 % wall time.  Used when every
      * query fits one stripe (the packed kernel has no rolling schedule); DPX_PACKED=0/1 overrides. */
-    /* Quad path (short reads, the reference's own dataset shape): queries of <= 256 rows in a batch large enough to fill
-     * the chip with a quarter of the waves run four pairs per wave, one per 16-lane DPP row; DPX_QUAD=0/1 overrides. */
+    /* Lane-packed path (short reads, the reference's own dataset shape): queries of <= 512 rows in a batch large enough to
+     * fill the chip with a fraction of the waves run several pairs per wave, ceil(m/8) lanes each (k_linear_lanes /
+     * k_affine_lanes, 8 x 8 tile layout); DPX_QUAD=0/1 overrides. */
     const bool linearAlgo = kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW;
     const bool quadAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
-    /* (four staged references per wave: keep the quad path to references that leave the LDS request small) */
-    const bool quadShape = quadAlgo && b->maxM <= 256 && b->maxM > 0 && b->maxN <= 2048;
-    bool useQuad = quadShape && numPairs >= 8192; /* measured crossover on short reads (tools/quad_threshold.py) */
+    /* (the staged references of a wave's pairs share its LDS: keep the path to references that leave the request small) */
+    const int kLanesR = lanes_rows(b->maxM, kernelAlgo);
+    const bool quadShape = quadAlgo && b->maxM <= 64 * kLanesR && b->maxM > 0 && b->maxN <= 4096;
+    bool useQuad = quadShape && b->maxM <= 256 && numPairs >= 8192; /* measured crossover on short reads (tools/quad_threshold.py) */
     if (const char *env = getenv("DPX_QUAD")) useQuad = atoi(env) != 0 && quadShape;
+    std::vector<dpx_wave_desc> waves;
+    size_t lanesRefArea = 0, lanesPairs = 0;
     if (useQuad) {
-        b->R = 8; /* empty pairs, if any, run on the one-pair-per-wave kernel at this tile height (they have no cells) */
+        b->R = kLanesR; /* empty pairs, if any, run on the one-pair-per-wave kernel at this tile height (they have no cells) */
         for (size_t i = 0; i < numPairs; i++) {
             dpx_pair_dev &pd = b->pairs[i];
-            if (pd.m > 0 && pd.n > 0) { couples.push_back((int32_t)i); pd.lanes = 16; pd.rows = pd.m <= 128 ? 8 : 16; }
+            if (pd.m > 0 && pd.n > 0) { couples.push_back((int32_t)i); pd.lanes = 16; pd.rows = kLanesR; }
             else singles.push_back((int32_t)i);
         }
-        /* 8-row pairs first, then 16-row pairs; inside a class the four pairs of a wave run max(n)+15 steps, so
-         * neighbours of similar reference length, longest first */
+        /* a wave runs max(n + lanes) steps: neighbours of similar reference length, longest first */
         std::stable_sort(couples.begin(), couples.end(), [&](int32_t x, int32_t y) {
             const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
-            if (X.rows != Y.rows) return X.rows < Y.rows;
             if (X.n != Y.n) return X.n > Y.n;
             return X.m > Y.m;
         });
-        for (int32_t c : couples) numQuad8 += b->pairs[c].rows == 8;
+        lanesPairs = couples.size();
         b->quad = !couples.empty();
-        if (!b->quad) { b->R = R; singles.clear(); }
+        if (b->quad) lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
+        else { b->R = R; singles.clear(); }
     }
     bool usePacked = !b->quad && b->store && linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1 &&
                      numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
@@ -616,7 +633,47 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         }
         b->packed = !couples.empty();
     }
-    if (b->packed || b->quad) {
+    trace.mark("create: validate+geometry+launch lists");
+    CREATE_TRY(stream_take(&b->stream));
+    trace.mark("create: stream");
+    int32_t *arenaOrder = nullptr, *arenaCouples = nullptr;
+    /* only the bytes this batch's pairs touch go to the device (a driver that cuts one big file into batches hands the
+     * whole file to every dpx_batch_create): upload [seqLo, seqHi) and rebase the device-side indices */
+    size_t seqLo = numBytes, seqHi = 0;
+    for (size_t i = 0; i < numPairs; i++) {
+        const dpx_pair_dev &pd = b->pairs[i];
+        seqLo = std::min(seqLo, (size_t)std::min(pd.refIdx, pd.qryIdx));
+        seqHi = std::max(seqHi, std::max((size_t)pd.refIdx + (size_t)pd.n, (size_t)pd.qryIdx + (size_t)pd.m));
+    }
+    if (seqHi <= seqLo) seqLo = seqHi = 0;
+    for (size_t i = 0; i < numPairs; i++) { b->pairs[i].refIdx -= (int32_t)seqLo; b->pairs[i].qryIdx -= (int32_t)seqLo; }
+    sequences += seqLo;
+    numBytes = seqHi - seqLo;
+    {
+        const size_t np1 = std::max<size_t>(numPairs, 1);
+        const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
+        const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
+        const size_t szCouples = std::max(szI32, align_up(waves.size() * sizeof(dpx_wave_desc), 256)); /* couples, or the wave descriptors */
+        const size_t need = szSeq + szPairs + 5 * szI32 + szCouples + szOff; /* score, endRow, endCol, order, couples, tbLen */
+        CREATE_TRY(g_arenaCache.take((void **)&b->arena, need, &b->arenaCap));
+        char *q = b->arena;
+        b->dSeq = q;                  q += szSeq;
+        b->dPairs = (dpx_pair_dev *)q; q += szPairs;
+        b->dScore = (int32_t *)q;     q += szI32;
+        b->dEndRow = (int32_t *)q;    q += szI32;
+        b->dEndCol = (int32_t *)q;    q += szI32;
+        b->dOrder = nullptr;          arenaOrder = (int32_t *)q; q += szI32;
+        b->dCouples = nullptr;        arenaCouples = (int32_t *)q; q += szCouples;
+        b->dTbLen = (int32_t *)q;     q += szI32;
+        b->dTbOff = (uint64_t *)q;
+    }
+    trace.mark("create: arena");
+    if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
+    trace.mark("create: H2D sequences");
+    if (b->quad) {
+        b->dCouples = arenaCouples;
+        CREATE_TRY(hipMemcpy(b->dCouples, waves.data(), waves.size() * sizeof(dpx_wave_desc), hipMemcpyHostToDevice));
+    } else if (b->packed) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     } else if (ragged) {
@@ -769,26 +826,18 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if (b->quad) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + four staged references */
-        const size_t refStride = align_up((size_t)b->maxN + 80, 16);
-        const size_t wpb = (size_t)dpx_quad_waves_per_block(kernelAlgo);
-        auto setup = [&](dpx_fill_args &k, int rows, size_t *ldsBytes) -> bool {
-            k = a;
-            k.ldsBufStride = (uint32_t)refStride;
-            k.ldsPerWave = (uint32_t)(dpx_quad_stage_bytes(kernelAlgo, rows, b->store) + 4 * refStride);
-            *ldsBytes = (size_t)k.ldsPerWave * wpb;
-            if (const char *env = getenv("DPX_LDS_PAD")) *ldsBytes += (size_t)std::max(0, atoi(env));
-            return *ldsBytes <= 160u * 1024u;
-        };
-        bool ok = setup(b->pkArgs, 8, &b->pkLdsBytes);
-        b->pkArgs.order = b->dCouples;
-        b->pkArgs.numPairs = (int32_t)numQuad8;
-        ok = setup(b->q16Args, 16, &b->q16LdsBytes) && ok;
-        b->q16Args.order = b->dCouples + numQuad8;
-        b->q16Args.numPairs = (int32_t)(couples.size() - numQuad8);
-        if (!ok) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+    if (b->quad) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + the staged references of its pairs */
+        dpx_fill_args &k = b->pkArgs;
+        k = a;
+        k.order = nullptr;
+        k.waves = reinterpret_cast<const dpx_wave_desc *>(b->dCouples);
+        k.numPairs = (int32_t)waves.size();
+        k.ldsPerWave = (uint32_t)(dpx_lanes_stage_bytes(kernelAlgo, kLanesR, b->store) + lanesRefArea);
+        b->pkLdsBytes = (size_t)k.ldsPerWave * (size_t)dpx_lanes_waves_per_block(kernelAlgo);
+        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
+        if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if ((b->packed || b->quad) && (numSingles > 0 || (b->quad && numQuad8 > 0 && couples.size() > numQuad8))) {
+    if ((b->packed || b->quad) && numSingles > 0) {
         /* more than one kernel per fill: a side stream + fork/join events (failure here only costs the overlap) */
         if (stream_take(&b->sideStream) != hipSuccess) { b->sideStream = nullptr; (void)hipGetLastError(); }
         if (b->sideStream && (hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming) != hipSuccess ||
@@ -796,22 +845,22 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     }
     b->nSingles = numSingles;
     b->nCouples = b->packed ? numCouples : 0;
-    b->nQuad8 = b->quad ? numQuad8 : 0;
-    b->nQuad16 = b->quad ? couples.size() - numQuad8 : 0;
+    b->nLanePairs = b->quad ? lanesPairs : 0;
+    b->nWaves = b->quad ? waves.size() : 0;
     *out = b;
     return DPX_OK;
 }
 
-/* One fill = up to three kernels over disjoint pairs (couples / quads of 8 and 16 rows per lane / leftover singles).  They do
- * not depend on each other, but launches on one stream run one after the other -- and the small ones (the 4 % of a
- * short-read batch with queries over 128 rows: 1000 waves on 1024 SIMDs) then cost a latency-bound tail of their own.
+/* One fill = up to two kernels over disjoint pairs (couples or lane-packed waves + leftover singles).  They do not depend
+ * on each other, but launches on one stream run one after the other -- and a small one (a few hundred leftover waves on
+ * 1024 SIMDs) then costs a latency-bound tail of its own.
  * The secondary kernels therefore go to the batch's side stream between a fork and a join event; on `s` the fill still
  * looks like one operation (events recorded on `s` around it time all of it). */
 static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     const bool hasMain = b->args.numPairs > 0;
     int kernels = 0;
     if (b->packed) kernels++;
-    if (b->quad) kernels += (b->pkArgs.numPairs > 0) + (b->q16Args.numPairs > 0);
+    if (b->quad) kernels++;
     if (hasMain) kernels++;
     hipStream_t side = s;
     bool forked = false;
@@ -823,16 +872,10 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
         forked = true;
     }
     hipError_t e = hipSuccess;
-    /* secondary kernels first (they are the short ones; the main kernel then fills the chip around them) */
+    /* secondary kernel first (it is the short one; the main kernel then fills the chip around it) */
     if (b->quad) {
-        if (b->pkArgs.numPairs > 0) { /* main: 8 rows per lane; secondary: 16 rows per lane, then empties */
-            if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->q16LdsBytes, side);
-            if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
-            if (e == hipSuccess) e = dpx_launch_fill_quad(b->pkArgs, b->kernelAlgo, 8, b->store, b->pkLdsBytes, s);
-        } else {
-            if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
-            if (e == hipSuccess) e = dpx_launch_fill_quad(b->q16Args, b->kernelAlgo, 16, b->store, b->q16LdsBytes, s);
-        }
+        if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side); /* empty pairs */
+        if (e == hipSuccess) e = dpx_launch_fill_lanes(b->pkArgs, b->kernelAlgo, b->R, b->store, b->pkLdsBytes, s);
     } else if (b->packed) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
         if (e == hipSuccess) e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
@@ -994,12 +1037,12 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
 int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
-    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? "k_banded_fill" : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_quad" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_quad" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? "k_banded_fill" : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_lanes" : "k_affine_fill")
+                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_lanes" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
-    snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu quad8=%zu quad16=%zu singles=%zu streams=%d",
-             names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nQuad8,
-             b->nQuad16, b->nSingles, (int)b->args.numStreams);
+    snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d",
+             names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
+             b->nWaves, b->nSingles, (int)b->args.numStreams);
     return DPX_OK;
 }
 

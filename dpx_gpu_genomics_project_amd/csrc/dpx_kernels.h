@@ -23,6 +23,7 @@ typedef struct dpx_fill_args {
     const char *seq;            /* flat sequence bytes (device copy of parseInput's buffer) */
     const dpx_pair_dev *pairs;  /* per-pair geometry + matrix offset */
     const int32_t *order;       /* optional launch order (longest pairs first) or NULL */
+    const dpx_wave_desc *waves; /* lane-packed kernels: one descriptor per wave (numPairs = number of waves) */
     int32_t numPairs;
     int32_t match, mismatch, gapOpen, gapExtend, band;
     int16_t *mat;               /* matrix pool (int16, engine layout) or NULL when score-only */
@@ -37,10 +38,11 @@ typedef struct dpx_fill_args {
 } dpx_fill_args;
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
-hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
-/* LDS of the quad kernels' line stage per wave (0 when score-only), and waves per workgroup of the kernel for `algo` */
-size_t dpx_quad_stage_bytes(int algo, int R, bool store);
-int dpx_quad_waves_per_block(int algo);
+hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);
+/* LDS in front of the staged references of a lane-packed wave (line stage, or the lane scratch when score-only), and
+ * waves per workgroup of the kernel for `algo` */
+size_t dpx_lanes_stage_bytes(int algo, int R, bool store);
+int dpx_lanes_waves_per_block(int algo);
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned char *stage_bytes(unsigned char *dst16, cons
     const unsigned a = (unsigned)(reinterpret_cast<uintptr_t>(src) & 15u);
     const u32x4 *from = reinterpret_cast<const u32x4 *>(src - a);
     u32x4 *to = reinterpret_cast<u32x4 *>(dst16);
-    const int blocks = (int)((a + (unsigned)n + 15u) >> 4);
+    const int blocks = n > 0 ? (int)((a + (unsigned)n + 15u) >> 4) : 0;
     for (int k = l; k < blocks; k += G) to[k] = from[k];
     return dst16 + a;
 }
@@ -437,35 +437,50 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
 }
 
 /* =====================================================================================================
- * Quad kernels for short queries (the reference's own dataset shape: reads of 80-150 bases, cuda/LNW V12 on
- * bsw/small): FOUR pairs per wave, one per 16-lane DPP row.  Lane l of a row owns rows [l*R, l*R+R) of its pair (16*R
- * rows: 128 at R = 8, 256 at R = 16), `up` moves with `v_mov_b32_dpp row_shr:1` (lanes 0/16/32/48 have no source and
- * keep the row-0 border), so the skew ramp is 15 steps instead of 63 and a 100-row query keeps 13 of 16 lanes busy
- * instead of 13 (or 25) of 64.  The four pairs may differ in shape: n, m, pointers are per-lane values, the wave runs
- * max(n)+15 steps and every row masks itself.
+ * Lane-packed kernels for short and medium queries (the reference's own dataset shape: reads of 80-150 bases,
+ * cuda/LNW V12 on bsw/small): SEVERAL pairs per wave.  A pair of m rows takes ceil(m/R) consecutive lanes (R = 8: 13
+ * lanes for a 100-row query), the host packs pairs of similar reference length into the 64 lanes of a wave
+ * (dpx_wave_desc: up to 8 slots), so nearly every lane owns rows -- one pair per wave kept 13 (or 25) of 64 lanes
+ * busy, round 1's four-per-wave quad kernels 13 of 16.  Lane l of a slot owns rows [l*R, l*R+R) and runs column
+ * j = t - l - d + 1 in step t (d = the slot's first lane mod 8, see below); `up` moves with v_mov_b32_dpp wave_shr:1,
+ * a slot's first lane takes the row-0 border instead; n, m, pointers are per-lane values, the wave runs
+ * max(n + lanes + d) steps and every lane masks itself.
  *
  * Writeback: 8 x 8 tile layout (dpx_layout.h), one whole 128-byte line per (row block, column block), through an LDS
- * transpose.  Per step a lane parks its 8 (16) new scores -- 16 B per row block -- in its own LDS line (ds_write_b128);
- * a lane's line is complete when its column index reaches a multiple of 8, which happens for the lanes
- * lambda = (t+1) mod 8 of every 8-lane group in step t: eight lines, read back so that lane x of the wave holds piece
- * x%8 of the line of lane 8*(x/8) + (t+1)%8 (ds_read_b128) and written by ONE global_store_dwordx4 of eight whole
- * lines.  Every stored byte is a cell (or the < 8-column tail of a pair's last column block): no skew-ramp padding, rows
- * rounded up to 8 instead of 64/128 -- round 1's [step][lane][rows] chunks wrote 1.40x the algorithmic bytes on short
- * reads.  LDS lines are 144 bytes apart and column c of lane lambda's line sits in slot (c + lambda) % 8 -- which is
- * t % 8 for every lane of the wave in step t, the skew cancels: conflict-free for the b128 write groups (8 contiguous
- * lanes, banks 4*lambda + const) and for the b128 read groups of MI355X_MICROARCH.md (4 x 16 lanes).  The store of the lines read in step t is issued in step
- * t+1, behind that step's arithmetic.
+ * transpose.  Per step a lane parks its R new scores -- 16 B per row block -- in its own LDS line (ds_write_b128); a
+ * lane's line is complete when its column index reaches a multiple of 8.  With the delay d that happens for the lanes
+ * lambda = (t+1) mod 8 of every 8-lane group in step t, whatever slots they belong to: eight lines, read back so that
+ * lane x of the wave holds piece x%8 of the line of lane 8*(x/8) + (t+1)%8 (ds_read_b128) and written by ONE
+ * global_store_dwordx4 of eight whole lines.  The fill is bound by store INSTRUCTIONS (about 104 cycles per
+ * global_store_dwordx4 and CU whether 64 or 48 lanes are active, profiles/README.md), so what counts is that every
+ * store instruction carries eight lines of real cells: no skew-ramp padding, rows rounded up to 8 instead of 64/128
+ * (round 1's [step][lane][rows] chunks wrote 1.40x the algorithmic bytes on short reads), no idle lanes.
+ * Where a line goes (pointer, column-block stride, the owner's skew and last column block) sits in the 16 spare bytes
+ * of the owner's LDS line; the reading lanes pick it up one step ahead.  LDS lines are 144 bytes apart and column c
+ * of lane lambda's line sits in slot (c + lambda) % 8 -- which is t % 8 for every lane of the wave in step t, the skew
+ * cancels: conflict-free for the b128 write groups (8 contiguous lanes, banks 4*lambda + const) and for the b128 read
+ * groups of MI355X_MICROARCH.md (4 x 16 lanes).  The store of the lines read in step t is issued in step t+1, behind
+ * that step's arithmetic.
  * ===================================================================================================== */
-__device__ __forceinline__ int row_shr1(int v, int lane0) { return __builtin_amdgcn_update_dpp(lane0, v, 0x111, 0xf, 0xf, false); }
+constexpr int kStageLine = 144; /* bytes between two LDS lines: 128 of cells + 16 of routing (StagePad) */
+constexpr int kLaneScratch = 1024; /* per wave: 16 B per lane for the end-of-pair reduction (aliases the line stage, which is dead by then) */
 
-constexpr int kStageLine = 144; /* bytes between two LDS lines */
 template <int Q, int PLANES>
 struct LineStage {
     static constexpr int kBytes = PLANES * Q * 64 * kStageLine; /* per wave */
     u32x4 pend[PLANES * Q];
     int16_t *pendDst = nullptr; /* line of (plane 0, sub-tile 0); plane p, sub-tile h: + (p*LB + h)*64 elements */
+    uint32_t pendLB = 0;
     int pendN = 0;              /* sub-tiles of the owner lane that hold rows (0: nothing to store) */
+    u32x4 route;                /* routing record of the owner whose lines complete in the NEXT step */
 
+    /* routing record of a lane, written once: {line pointer lo, hi, column-block stride (elements), skew | n8 << 8 | valid sub-tiles << 24 | LB << 26 ...} */
+    static __device__ __forceinline__ void set_route(unsigned char *tile, int lane, const int16_t *line0, uint32_t cs, int skew, int n8,
+                                                     int nValid, uint32_t LB) {
+        const uintptr_t ptr = reinterpret_cast<uintptr_t>(line0);
+        u32x4 r = {(uint32_t)ptr, (uint32_t)(ptr >> 32), cs | (LB << 20), (uint32_t)skew | ((uint32_t)n8 << 8) | ((uint32_t)nValid << 28)};
+        *reinterpret_cast<u32x4 *>(tile + lane * kStageLine + 128) = r;
+    }
     /* park the lane's 8 rows of sub-tile h, plane p, in slot t % 8 of its line (t = the wave's step) */
     static __device__ __forceinline__ void put(unsigned char *tile, int lane, int p, int h, int t, u32x4 v) {
 #if DPX_EXP_QUAD == 2
@@ -474,7 +489,7 @@ struct LineStage {
         *reinterpret_cast<u32x4 *>(tile + ((p * Q + h) * 64 + lane) * kStageLine + ((t & 7) << 4)) = v;
     }
     /* write out what fetch() read one step ago */
-    __device__ __forceinline__ void store(const uint32_t LB) {
+    __device__ __forceinline__ void store() {
 #if DPX_EXP_QUAD == 1
         if (pendN == 77) /* never */
 #endif
@@ -482,12 +497,24 @@ struct LineStage {
         for (int h = 0; h < Q; h++) {
             if (h < pendN) {
 #pragma unroll
-                for (int p = 0; p < PLANES; p++) stream_store(reinterpret_cast<u32x4 *>(pendDst + ((size_t)(p * LB + h) << 6)), pend[p * Q + h]);
+                for (int p = 0; p < PLANES; p++) stream_store(reinterpret_cast<u32x4 *>(pendDst + ((size_t)(p * pendLB + h) << 6)), pend[p * Q + h]);
             }
         }
     }
-    /* read piece lane%8 of the lines of lane `owner` (wave lane number) */
-    __device__ __forceinline__ void fetch(const unsigned char *tile, int lane, int owner, int nValid, int16_t *dst) {
+    __device__ __forceinline__ void fetch_route(const unsigned char *tile, int lane, int tNext) {
+        route = *reinterpret_cast<const u32x4 *>(tile + ((lane & ~7) | ((tNext + 1) & 7)) * kStageLine + 128);
+    }
+    /* step t: read piece lane%8 of the lines that completed in this step (owner = lane (t+1)%8 of this lane's 8-group),
+     * routed by the record fetch_route(t) brought in during the previous step */
+    __device__ __forceinline__ void fetch(const unsigned char *tile, int lane, int t) {
+        const int owner = (lane & ~7) | ((t + 1) & 7);
+        const int jg = t + 1 - (int)(route.w & 0xFFu);           /* owner's column: a multiple of 8 */
+        const int n8 = (int)((route.w >> 8) & 0xFFFFFu);
+        const bool ok = jg >= 8 && jg <= n8;
+        int16_t *line0 = reinterpret_cast<int16_t *>((uintptr_t)route.x | ((uintptr_t)route.y << 32));
+        pendDst = line0 + (size_t)((jg >> 3) - 1) * (size_t)(route.z & 0xFFFFFu) + ((lane & 7) << 3);
+        pendLB = route.z >> 20;
+        pendN = ok ? (int)(route.w >> 28) : 0;
 #pragma unroll
         for (int p = 0; p < PLANES; p++)
 #pragma unroll
@@ -497,33 +524,54 @@ struct LineStage {
 #else
                 pend[p * Q + h] = *reinterpret_cast<const u32x4 *>(tile + ((p * Q + h) * 64 + owner) * kStageLine + (((lane + owner) & 7) << 4));
 #endif
-        pendN = nValid;
-        pendDst = dst;
     }
 };
 
+/* what a lane learns from the wave's descriptor */
+struct LaneSlot {
+    bool has;
+    int p, l, num, d; /* pair, lane inside the slot, lanes of the slot, start delay (first lane mod 8) */
+    uint32_t refOff;  /* LDS byte offset of the slot's staged reference inside the wave's reference area */
+};
+__device__ __forceinline__ LaneSlot find_slot(const dpx_wave_desc *wd, const int lane) {
+    LaneSlot s{false, 0, 0, 0, 0, 0u};
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(wd); /* wave-uniform address: 16 dwords through scalar loads */
+#pragma unroll
+    for (int k = 0; k < DPX_WAVE_SLOTS; k++) {
+        const int f = (int)((w[8 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu), c = (int)((w[10 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu);
+        const uint32_t ro = (w[12 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
+        if (lane >= f && lane < f + c) { s.has = true; s.p = (int)w[k]; s.l = lane - f; s.num = c; s.d = f & 7; s.refOff = ro << 4; }
+    }
+    return s;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 template <int R, bool LOCAL, bool STORE>
-__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill_args a) {
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Q = R / 8;
     using Stage = LineStage<Q, 1>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
-    if (4 * w >= a.numPairs) return; /* wave-uniform */
-    const int q = lane >> 4, l = lane & 15;
-    const int slot = 4 * w + q;
-    const bool has = slot < a.numPairs;
-    const int p = has ? (a.order ? a.order[slot] : slot) : 0;
+    if (w >= a.numPairs) return; /* wave-uniform; numPairs = number of wave descriptors */
+    const LaneSlot sl = find_slot(a.waves + w, lane);
+    const bool has = sl.has;
+    const int p = sl.p, l = sl.l;
     const dpx_pair_dev pr = a.pairs[p];
-    const int n = has ? pr.n : 0, m = has ? pr.m : 0; /* per DPP row */
+    const int n = has ? pr.n : 0, m = has ? pr.m : 0;
     const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
-    unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;                       /* the wave's line stage */
-    unsigned char *refl = tileL + (STORE ? Stage::kBytes : 0) + (size_t)q * a.ldsBufStride; /* this row's reference: [16 + (j-1)] */
-    const unsigned char *refs = stage_bytes(refl + 16, ref, n, l, 16);
+    unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;      /* [line stage | lane scratch][staged references] */
+    unsigned char *scratch = tileL;
+    unsigned char *refl = tileL + (STORE ? Stage::kBytes : kLaneScratch) + sl.refOff;
+    const unsigned char *refs = stage_bytes(refl, ref, n, l, max(sl.num, 1));
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
@@ -536,21 +584,23 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
     }
     st.dtop = LOCAL ? 0 : row0 * gap;
 
-    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
-                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
-    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
-    int16_t *matp = a.mat + pr.matOff + ((size_t)(lane & 7) << 3); /* this lane's 16-byte piece of a line */
+    const int skew = l + sl.d; /* this lane runs column j = t - skew + 1 in step t */
     const int n8 = (n + 7) & ~7;
-    const unsigned char *rp = refs - l; /* rp[t] = reference character of column j = t - l + 1 */
+    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
+    if constexpr (STORE)
+        Stage::set_route(tileL, lane, a.mat + pr.matOff + ((size_t)(l * Q) << 6), cs, skew, n8, has ? min(max((int)LB - l * Q, 0), Q) : 0, LB);
+    const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
+    const unsigned char *rp = refs - skew; /* rp[t] = reference character of column j = t - skew + 1 */
     int rcN = rp[0];
     Stage stage;
-    const int steps = (STORE ? ((nmax + 7) & ~7) : nmax) + 15;
-    auto quad_step = [&](const int t) {
-        const int j = t - l + 1;
+    if constexpr (STORE) stage.fetch_route(tileL, lane, 0);
+    auto lane_step = [&](const int t) {
+        const int j = t - skew + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
-        const int upin = row_shr1(st.Hl[R - 1], LOCAL ? 0 : (t + 1) * gap); /* lanes 0/16/32/48: row-0 border of column t+1 */
-        const bool active = has && nrows > 0 && j >= 1 && j <= n;
+        const int sh = wave_shr1(st.Hl[R - 1], 0);
+        const int upin = (l == 0) ? (LOCAL ? 0 : j * gap) : sh; /* a slot's first lane: row-0 border of its column */
+        const bool active = nrows > 0 && j >= 1 && j <= n;
         if (active) lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
         if constexpr (STORE) {
             if (active) {
@@ -562,43 +612,40 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_quad(const dpx_fill
                     Stage::put(tileL, lane, 0, h, t, v);
                 }
             }
-            stage.store(LB);
-            /* the lanes (t+1)%8 of every 8-lane group have just finished a column block (or ran past the pair's last,
-             * partial one): this lane fetches piece lane%8 of its group's line */
-            const int lg = (l & 8) | ((t + 1) & 7); /* owner's lane inside the pair */
-            const int jg = t - lg + 1;              /* owner's column: a multiple of 8 */
-            const int nValid = (has && jg >= 8 && jg <= n8) ? min(max((int)LB - lg * Q, 0), Q) : 0; /* row blocks of the owner that exist */
-            stage.fetch(tileL, lane, (lane & ~7) | ((t + 1) & 7), nValid, matp + (size_t)((jg >> 3) - 1) * cs + ((size_t)(lg * Q) << 6));
+            stage.store();
+            stage.fetch(tileL, lane, t);
+            stage.fetch_route(tileL, lane, t + 1);
         }
     };
     {
         int t = 0;
         for (; t + 1 < steps; t += 2) { /* two steps per trip (registers swap roles instead of moving, keys fold with max3) */
-            quad_step(t);
-            quad_step(t + 1);
+            lane_step(t);
+            lane_step(t + 1);
         }
-        if (t < steps) quad_step(t);
+        if (t < steps) lane_step(t);
     }
-    if constexpr (STORE) stage.store(LB);
-    if (!has) return;
+    if constexpr (STORE) stage.store();
     if constexpr (LOCAL) {
+        /* first strict maximum in row-major order over the slot's lanes (rows ascend with the lane): the slot's first lane
+         * scans its lanes' (score, row, column) in the lane scratch */
         int bestv = 0, bestrow = 0, bestcol = 0;
         lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
-        const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
-        unsigned long long top = mine;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { /* xor offsets < 16 stay inside the 16-lane row */
-            const unsigned long long o = __shfl_xor(top, off, 64);
-            top = o > top ? o : top;
-        }
-        if ((int)(top >> 32) == 0) {
-            if (l == 0) { a.score[p] = 0; a.endRow[p] = 0; a.endCol[p] = 0; }
-        } else if (mine == top) {
-            a.score[p] = bestv; a.endRow[p] = bestrow; a.endCol[p] = bestcol;
+        int *mine = reinterpret_cast<int *>(scratch + lane * 16);
+        mine[0] = bestv; mine[1] = bestrow; mine[2] = bestcol;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the other lanes' entries are read below: keep the order */
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (has && l == 0) {
+            for (int k = 1; k < sl.num; k++) {
+                const int *o = reinterpret_cast<const int *>(scratch + (lane + k) * 16);
+                if (o[0] > bestv) { bestv = o[0]; bestrow = o[1]; bestcol = o[2]; }
+            }
+            a.score[p] = bestv; a.endRow[p] = bestv > 0 ? bestrow : 0; a.endCol[p] = bestv > 0 ? bestcol : 0;
         }
     } else {
         const int lm = (m - 1) / R, rm = (m - 1) % R; /* owner of row m: its registers hold column n after its last step */
-        if (l == lm) {
+        if (has && l == lm) {
             int v = st.Hl[0];
 #pragma unroll
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
@@ -1222,24 +1269,23 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
     }
 }
 
-/* Affine quad kernel: the Gotoh recurrence of k_affine_fill on the four-pairs-per-wave schedule of k_linear_quad
- * (16 lanes per pair, `up` of H and D through row_shr:1); the three planes H, I, D leave through the same LDS line
- * stage into the 8 x 8 tile layout, three whole-line stores per step.  One wave per workgroup: the stage needs
- * 27 KiB of LDS per wave (three planes), so small workgroups keep five of them on a CU. */
-#define DPX_AQUAD_THREADS 64
+/* Affine lane-packed kernel: the Gotoh recurrence of k_affine_fill on the several-pairs-per-wave schedule of
+ * k_linear_lanes (`up` of H and D through wave_shr:1, a slot's first lane takes the row-0 borders); the three planes H,
+ * I, D leave through the same LDS line stage into the 8 x 8 tile layout, three whole-line stores per step.  One wave per
+ * workgroup: the stage needs 27 KiB of LDS per wave (three planes), so small workgroups keep five of them on a CU. */
+#define DPX_ALANES_THREADS 64
 template <int R, bool STORE>
-__global__ void __launch_bounds__(DPX_AQUAD_THREADS) k_affine_quad(const dpx_fill_args a) {
+__global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Q = R / 8;
     using Stage = LineStage<Q, 3>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * (DPX_AQUAD_THREADS / 64) + wv;
-    if (4 * w >= a.numPairs) return; /* wave-uniform */
-    const int q = lane >> 4, l = lane & 15;
-    const int slot = 4 * w + q;
-    const bool has = slot < a.numPairs;
-    const int p = has ? (a.order ? a.order[slot] : slot) : 0;
+    const int w = blockIdx.x * (DPX_ALANES_THREADS / 64) + wv;
+    if (w >= a.numPairs) return; /* wave-uniform; numPairs = number of wave descriptors */
+    const LaneSlot sl = find_slot(a.waves + w, lane);
+    const bool has = sl.has;
+    const int p = sl.p, l = sl.l;
     const dpx_pair_dev pr = a.pairs[p];
     const int n = has ? pr.n : 0, m = has ? pr.m : 0;
     const int match = a.match, mismatch = a.mismatch;
@@ -1248,8 +1294,8 @@ __global__ void __launch_bounds__(DPX_AQUAD_THREADS) k_affine_quad(const dpx_fil
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
     unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;
-    unsigned char *refl = tileL + (STORE ? Stage::kBytes : 0) + (size_t)q * a.ldsBufStride;
-    const unsigned char *refs = stage_bytes(refl + 16, ref, n, l, 16);
+    unsigned char *refl = tileL + (STORE ? Stage::kBytes : kLaneScratch) + sl.refOff;
+    const unsigned char *refs = stage_bytes(refl, ref, n, l, max(sl.num, 1));
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
@@ -1263,26 +1309,28 @@ __global__ void __launch_bounds__(DPX_AQUAD_THREADS) k_affine_quad(const dpx_fil
     }
     st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
 
-    const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)),
-                         max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
-    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
-    int16_t *matp = a.mat + pr.matOff + ((size_t)(lane & 7) << 3);
+    const int skew = l + sl.d;
     const int n8 = (n + 7) & ~7;
-    const unsigned char *rp = refs - l;
+    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
+    if constexpr (STORE)
+        Stage::set_route(tileL, lane, a.mat + pr.matOff + ((size_t)(l * Q) << 6), cs, skew, n8, has ? min(max((int)LB - l * Q, 0), Q) : 0, LB);
+    const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
+    const unsigned char *rp = refs - skew;
     int rcN = rp[0];
     Stage stage;
-    const int steps = (STORE ? ((nmax + 7) & ~7) : nmax) + 15;
+    if constexpr (STORE) stage.fetch_route(tileL, lane, 0);
     auto pack8 = [](const int *v) -> u32x4 {
         u32x4 w = {pack_lo16(v[0], v[1]), pack_lo16(v[2], v[3]), pack_lo16(v[4], v[5]), pack_lo16(v[6], v[7])};
         return w;
     };
-    auto quad_step = [&](const int t) {
-        const int j = t - l + 1;
+    auto lane_step = [&](const int t) {
+        const int j = t - skew + 1;
         const int rc = rcN;
         rcN = rp[t + 1];
-        const int upH = row_shr1(st.Hl[R - 1], o + (t + 1) * e); /* row-0 border H[0][j] = o + j*e (:50-53) */
-        const int upD = row_shr1(st.Dl[R - 1], DPX_NEG);         /* virtual D[0][j] */
-        const bool active = has && nrows > 0 && j >= 1 && j <= n;
+        const int shH = wave_shr1(st.Hl[R - 1], 0), shD = wave_shr1(st.Dl[R - 1], 0);
+        const int upH = (l == 0) ? o + j * e : shH;   /* row-0 border H[0][j] = o + j*e (:50-53) */
+        const int upD = (l == 0) ? DPX_NEG : shD;     /* virtual D[0][j] */
+        const bool active = nrows > 0 && j >= 1 && j <= n;
         if (active) aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
         if constexpr (STORE) {
             if (active) {
@@ -1293,25 +1341,22 @@ __global__ void __launch_bounds__(DPX_AQUAD_THREADS) k_affine_quad(const dpx_fil
                     Stage::put(tileL, lane, 2, h, t, pack8(&st.Dl[8 * h]));
                 }
             }
-            stage.store(LB);
-            const int lg = (l & 8) | ((t + 1) & 7);
-            const int jg = t - lg + 1;
-            const int nValid = (has && jg >= 8 && jg <= n8) ? min(max((int)LB - lg * Q, 0), Q) : 0; /* row blocks of the owner that exist */
-            stage.fetch(tileL, lane, (lane & ~7) | ((t + 1) & 7), nValid, matp + (size_t)((jg >> 3) - 1) * cs + ((size_t)(lg * Q) << 6));
+            stage.store();
+            stage.fetch(tileL, lane, t);
+            stage.fetch_route(tileL, lane, t + 1);
         }
     };
     {
         int t = 0;
         for (; t + 1 < steps; t += 2) {
-            quad_step(t);
-            quad_step(t + 1);
+            lane_step(t);
+            lane_step(t + 1);
         }
-        if (t < steps) quad_step(t);
+        if (t < steps) lane_step(t);
     }
-    if constexpr (STORE) stage.store(LB);
-    if (!has) return;
+    if constexpr (STORE) stage.store();
     const int lm = (m - 1) / R, rm = (m - 1) % R;
-    if (l == lm) {
+    if (has && l == lm) {
         int v = st.Hl[0];
 #pragma unroll
         for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
@@ -1895,16 +1940,17 @@ hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, 
     return hipErrorInvalidValue;
 }
 
-/* quad kernels (short queries): a.order = pair slots, 4 per wave; a.numPairs = number of slots.  ldsBytes is per
- * workgroup: dpx_quad_lds_per_wave() x waves per workgroup (4 for the linear kernels, 1 for the affine one). */
-size_t dpx_quad_stage_bytes(int algo, int R, bool store) {
-    if (!store) return 0;
+/* lane-packed kernels (short / medium queries): a.waves = one descriptor per wave, a.numPairs = number of waves.
+ * ldsBytes is per workgroup: (dpx_lanes_stage_bytes() + reference area) x waves per workgroup (4 for the linear kernels,
+ * 1 for the affine one). */
+size_t dpx_lanes_stage_bytes(int algo, int R, bool store) {
+    if (!store) return (size_t)kLaneScratch;
     return (size_t)(algo == DPX_K_ANW ? 3 : 1) * (size_t)(R / 8) * 64u * (size_t)kStageLine;
 }
-int dpx_quad_waves_per_block(int algo) { return algo == DPX_K_ANW ? DPX_AQUAD_THREADS / 64 : DPX_FILL_THREADS / 64; }
+int dpx_lanes_waves_per_block(int algo) { return algo == DPX_K_ANW ? DPX_ALANES_THREADS / 64 : DPX_FILL_THREADS / 64; }
 
 template <class K>
-static hipError_t launch_quad_kernel(K kernel, const dpx_fill_args &a, dim3 grid, int threads, size_t lds, hipStream_t s) {
+static hipError_t launch_lanes_kernel(K kernel, const dpx_fill_args &a, dim3 grid, int threads, size_t lds, hipStream_t s) {
     if (lds > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1913,32 +1959,30 @@ static hipError_t launch_quad_kernel(K kernel, const dpx_fill_args &a, dim3 grid
     return hipGetLastError();
 }
 
-hipError_t dpx_launch_fill_quad(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
+hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int pairsPerBlock = 4 * dpx_quad_waves_per_block(algo);
-    dim3 grid((unsigned)((a.numPairs + pairsPerBlock - 1) / pairsPerBlock));
+    const int wpb = dpx_lanes_waves_per_block(algo);
+    dim3 grid((unsigned)((a.numPairs + wpb - 1) / wpb));
     if (algo == DPX_K_ANW) {
-        const int th = DPX_AQUAD_THREADS;
-        if (R == 8) return store ? launch_quad_kernel(k_affine_quad<8, true>, a, grid, th, ldsBytes, stream)
-                                 : launch_quad_kernel(k_affine_quad<8, false>, a, grid, th, ldsBytes, stream);
-        if (R == 16) return store ? launch_quad_kernel(k_affine_quad<16, true>, a, grid, th, ldsBytes, stream)
-                                  : launch_quad_kernel(k_affine_quad<16, false>, a, grid, th, ldsBytes, stream);
+        const int th = DPX_ALANES_THREADS;
+        if (R == 8) return store ? launch_lanes_kernel(k_affine_lanes<8, true>, a, grid, th, ldsBytes, stream)
+                                 : launch_lanes_kernel(k_affine_lanes<8, false>, a, grid, th, ldsBytes, stream);
         return hipErrorInvalidValue;
     }
     const bool local = algo == DPX_K_LSW;
     const int th = DPX_FILL_THREADS;
-#define DPX_QUAD_CASE(R_)                                                                                              \
-    case R_:                                                                                                          \
-        if (local) return store ? launch_quad_kernel(k_linear_quad<R_, true, true>, a, grid, th, ldsBytes, stream)    \
-                                : launch_quad_kernel(k_linear_quad<R_, true, false>, a, grid, th, ldsBytes, stream);  \
-        return store ? launch_quad_kernel(k_linear_quad<R_, false, true>, a, grid, th, ldsBytes, stream)              \
-                     : launch_quad_kernel(k_linear_quad<R_, false, false>, a, grid, th, ldsBytes, stream);
+#define DPX_LANES_CASE(R_)                                                                                              \
+    case R_:                                                                                                           \
+        if (local) return store ? launch_lanes_kernel(k_linear_lanes<R_, true, true>, a, grid, th, ldsBytes, stream)    \
+                                : launch_lanes_kernel(k_linear_lanes<R_, true, false>, a, grid, th, ldsBytes, stream);  \
+        return store ? launch_lanes_kernel(k_linear_lanes<R_, false, true>, a, grid, th, ldsBytes, stream)              \
+                     : launch_lanes_kernel(k_linear_lanes<R_, false, false>, a, grid, th, ldsBytes, stream);
     switch (R) {
-        DPX_QUAD_CASE(8)
-        DPX_QUAD_CASE(16)
+        DPX_LANES_CASE(8)
+        DPX_LANES_CASE(16)
     default: return hipErrorInvalidValue;
     }
-#undef DPX_QUAD_CASE
+#undef DPX_LANES_CASE
 }
 
 /* stream schedule (uniform batches): a.numStreams persistent waves, each fills its pairs back to back */

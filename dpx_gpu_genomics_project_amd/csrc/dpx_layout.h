@@ -51,6 +51,17 @@ typedef struct dpx_pair_dev {
     uint16_t rows;        /* rows per lane of the kernel that fills this pair (quad batches mix 8 and 16); 0 = the batch's */
 } dpx_pair_dev;
 
+/* Lane-packed kernels (k_linear_lanes / k_affine_lanes): what one wave aligns.  Up to DPX_WAVE_SLOTS pairs share the 64
+ * lanes; slot k owns lanes [first[k], first[k] + num[k]) with num = ceil(m / rows per lane).  Built by the host
+ * (dpx_capi.cpp: pack_waves), read through scalar loads. */
+#define DPX_WAVE_SLOTS 8
+typedef struct dpx_wave_desc {
+    int32_t pair[DPX_WAVE_SLOTS];    /* batch index of the slot's pair */
+    uint8_t first[DPX_WAVE_SLOTS];   /* first lane */
+    uint8_t num[DPX_WAVE_SLOTS];     /* lanes (0: slot unused) */
+    uint16_t refOff[DPX_WAVE_SLOTS]; /* LDS offset / 16 of the slot's staged reference inside the wave's reference area */
+} dpx_wave_desc;
+
 /* number of stripes / elements of one pair's block */
 DPX_HD int dpx_tiled_stripes(int m, int R) { return (m + 64 * R - 1) / (64 * R); }
 DPX_HD uint64_t dpx_tiled_chunks(int m, int n, int R) { /* steps (chunks) of one pair */

@@ -51,6 +51,23 @@ def test_quad_uniform_shapes(gpu, algo, monkeypatch):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, monkeypatch):
+    """Lane-packed kernels at their limits: 8 rows per lane up to 512 query rows (64 lanes), 16 rows per lane (two row blocks
+    per lane, linear-gap kernels only) up to 1024; mixes where a wave holds one long and several short pairs."""
+    monkeypatch.setenv("DPX_QUAD", "1")
+    shapes = [(512, 300), (505, 77), (300, 520)] + ([(513, 200), (1024, 1024), (700, 90), (1000, 7)] if algo != "ANW" else [])
+    for i, (m, n) in enumerate(shapes):
+        sb = make_batch(3, m, n, seed=900 + i, first_index=95)
+        with gpu.Batch({"LNW": 0, "LSW": 1, "ANW": 2}[algo], sb.sequences, sb.pairs, *W3[algo]) as b:
+            d = b.describe()
+            assert d["kernel"].endswith("_lanes") and d["rows_per_lane"] == (8 if m <= 512 else 16), d
+        _check(gpu, algo, sb, W3[algo])
+    _check(gpu, algo, make_ragged_batch(40, 20, 500, 30, 400, seed=35), W3[algo], every=4)
+    if algo != "ANW":
+        _check(gpu, algo, make_ragged_batch(30, 20, 1024, 30, 600, seed=36), W5[algo], every=5)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 def test_quad_ragged_and_empty(gpu, algo, monkeypatch):
     """Waves whose four pairs differ in both lengths; empty sequences are split off to the one-pair-per-wave kernel."""
     monkeypatch.setenv("DPX_QUAD", "1")
