@@ -13,14 +13,15 @@ import numpy as np
 
 ALGO_LNW, ALGO_LSW, ALGO_ANW, ALGO_BSW = 0, 1, 2, 3
 ALGO_NAMES = {ALGO_LNW: "LNW", ALGO_LSW: "LSW", ALGO_ANW: "ANW", ALGO_BSW: "BSW"}
-KEEP_MATRICES, SCORE_ONLY = 0x0, 0x1
+KEEP_MATRICES, SCORE_ONLY, TIME_FILLS = 0x0, 0x1, 0x2
 MAT_H, MAT_I, MAT_D = 0, 1, 2
 
 # every symbol include/dpx_align.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_strerror", "dpx_last_error",
-    "dpx_abi_version", "dpx_batch_create", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_sync",
+    "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_sync",
     "dpx_batch_device_results", "dpx_batch_results", "dpx_batch_matrix", "dpx_batch_traceback",
+    "dpx_batch_output_begin", "dpx_batch_output_end", "dpx_batch_output_take", "dpx_text_free",
     "dpx_batch_info", "dpx_batch_describe", "dpx_batch_destroy", "dpx_align_batch", "dpx_prim_eval",
 )
 
@@ -70,13 +71,20 @@ def load() -> C.CDLL:
     lib.dpx_last_error.restype = C.c_char_p
     lib.dpx_batch_create.argtypes = [C.POINTER(Params), vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint,
                                      C.POINTER(vp)]
+    lib.dpx_batch_create_on.argtypes = [C.c_int, C.POINTER(Params), vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint,
+                                        C.POINTER(vp)]
     lib.dpx_batch_fill.argtypes = [vp, vp]
     lib.dpx_batch_fill_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    lib.dpx_batch_last_fill_usec.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dpx_batch_sync.argtypes = [vp]
     lib.dpx_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.dpx_batch_results.argtypes = [vp, vp, vp, vp]
     lib.dpx_batch_matrix.argtypes = [vp, C.c_size_t, C.c_int, vp]
     lib.dpx_batch_traceback.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, i32p]
+    lib.dpx_batch_output_begin.argtypes = [vp, C.c_uint64]
+    lib.dpx_batch_output_end.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint64))]
+    lib.dpx_batch_output_take.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.dpx_text_free.argtypes = [vp]
     lib.dpx_batch_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64)]
     lib.dpx_batch_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
@@ -120,7 +128,7 @@ class Batch:
 
     def __init__(self, algo: int, sequences: np.ndarray, pairs: np.ndarray, match: int = 3, mismatch: int = -1,
                  gap_open: int = -2, gap_extend: int = -1, band: int = 0, flags: int = KEEP_MATRICES,
-                 first_pair: int = 0, num_pairs: Optional[int] = None):
+                 first_pair: int = 0, num_pairs: Optional[int] = None, device: int = -1):
         lib = load()
         self._lib = lib
         self._h = C.c_void_p(None)
@@ -131,8 +139,8 @@ class Batch:
         self.params = Params(algo, match, mismatch, gap_open, gap_extend, band)
         self.pairs = prs[first_pair:first_pair + num_pairs].copy()
         self.num_pairs = num_pairs
-        rc = lib.dpx_batch_create(C.byref(self.params), seq.ctypes.data, seq.size, prs.ctypes.data, first_pair,
-                                  num_pairs, flags, C.byref(self._h))
+        rc = lib.dpx_batch_create_on(device, C.byref(self.params), seq.ctypes.data, seq.size, prs.ctypes.data, first_pair,
+                                     num_pairs, flags, C.byref(self._h))
         _check(rc, "dpx_batch_create")
 
     def fill(self, stream: int = 0) -> None:
@@ -174,6 +182,17 @@ class Batch:
         _check(self._lib.dpx_batch_traceback(self._h, pair, a, b, c, C.byref(ln)), "dpx_batch_traceback")
         k = ln.value
         return a.raw[:k].decode("latin-1"), b.raw[:k].decode("latin-1"), c.raw[:k].decode("latin-1")
+
+    def output_begin(self, first_pair_number: int = 0) -> None:
+        """Start building the batch's result text on the device (asynchronous)."""
+        _check(self._lib.dpx_batch_output_begin(self._h, first_pair_number), "dpx_batch_output_begin")
+
+    def output_end(self) -> Tuple[bytes, np.ndarray]:
+        """(text, offsets): the reference's stdout blocks of every pair, and numPairs + 1 byte offsets into it."""
+        text, nbytes, offs = C.c_char_p(), C.c_size_t(0), C.POINTER(C.c_uint64)()
+        _check(self._lib.dpx_batch_output_end(self._h, C.byref(text), C.byref(nbytes), C.byref(offs)), "dpx_batch_output_end")
+        raw = C.string_at(text, nbytes.value)
+        return raw, np.ctypeslib.as_array(offs, shape=(self.num_pairs + 1,)).copy()
 
     def info(self) -> dict:
         npairs, cells, mb, ab = C.c_size_t(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -25,7 +25,8 @@
 namespace {
 
 std::mutex g_mu;
-int g_device = -1;
+int g_device = -1;             /* default device: the one dpx_init() bound (dpx_batch_create, dpx_device_info, dpx_prim_eval) */
+thread_local int t_device = -1; /* device of the call this thread is in (a batch's own device, or the default) */
 thread_local std::string t_err;
 
 int hip_fail(hipError_t e, const char *what) {
@@ -39,12 +40,19 @@ int hip_fail(hipError_t e, const char *what) {
         if (e__ != hipSuccess) return hip_fail(e__, #call); \
     } while (0)
 
-int bind_device() {
-    if (g_device < 0) {
-        int rc = dpx_init(0);
-        if (rc != DPX_OK) return rc;
+/* Make `device` (-1: the default device, initialising device 0 if dpx_init() was never called) current for this thread.
+ * Every buffer / stream cache entry carries its device, so one process can drive several GPUs: a batch lives on the
+ * device it was created on and every call on it binds that device first. */
+int bind_device(int device = -1) {
+    if (device < 0) {
+        if (g_device < 0) {
+            int rc = dpx_init(0);
+            if (rc != DPX_OK) return rc;
+        }
+        device = g_device;
     }
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(device));
+    t_device = device;
     return DPX_OK;
 }
 
@@ -91,7 +99,7 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual) {
         size_t best = parked_.size();
         for (size_t i = 0; i < parked_.size(); i++) {
             const Entry &e = parked_[i];
-            if (e.device != g_device || e.bytes < need || e.bytes > need + need / 2 + (1u << 20)) continue;
+            if (e.device != t_device || e.bytes < need || e.bytes > need + need / 2 + (1u << 20)) continue;
             if (best == parked_.size() || e.bytes < parked_[best].bytes) best = i;
         }
         if (best != parked_.size()) {
@@ -102,11 +110,15 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual) {
             return hipSuccess;
         }
     }
-    *actual = need;
-    hipError_t e = raw_alloc(out, need);
+    /* a fresh buffer gets 1/8 of headroom (and a 64 KiB granule) so that the next batch of about the same size can take
+     * it over: batches of one file differ by a few per cent, and pinning 8 MB costs ~1 ms every time it misses */
+    const size_t want = need < ((size_t)1 << 30) ? align_up(need + need / 8, (size_t)64 << 10) : need;
+    *actual = want;
+    hipError_t e = raw_alloc(out, want);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         trim_all_caches();
+        *actual = need;
         e = raw_alloc(out, need);
     }
     return e;
@@ -117,12 +129,12 @@ void BufCache::park(void *ptr, size_t bytes) {
     std::vector<void *> evicted;
     {
         std::lock_guard<std::mutex> lk(mu_);
-        if (g_device < 0 || bytes > maxBytes_) {
+        if (t_device < 0 || bytes > maxBytes_) {
             evicted.push_back(ptr);
         } else {
-            const size_t big = (size_t)1 << 30; /* at most one parked buffer of a GiB or more */
+            const size_t big = (size_t)1 << 30; /* at most one parked buffer of a GiB or more per device */
             for (size_t i = 0; i < parked_.size();) {
-                const bool drop = (bytes >= big && parked_[i].bytes >= big) || parked_[i].device != g_device;
+                const bool drop = bytes >= big && parked_[i].bytes >= big && parked_[i].device == t_device; /* per device */
                 if (drop) { evicted.push_back(parked_[i].ptr); total_ -= parked_[i].bytes; parked_.erase(parked_.begin() + (long)i); }
                 else i++;
             }
@@ -131,7 +143,7 @@ void BufCache::park(void *ptr, size_t bytes) {
                 total_ -= parked_.front().bytes;
                 parked_.erase(parked_.begin());
             }
-            parked_.push_back(Entry{ptr, bytes, g_device});
+            parked_.push_back(Entry{ptr, bytes, t_device});
             total_ += bytes;
         }
     }
@@ -162,7 +174,7 @@ hipError_t stream_take(hipStream_t *out) {
     {
         std::lock_guard<std::mutex> lk(g_streams.mu);
         for (size_t i = 0; i < g_streams.parked.size(); i++)
-            if (g_streams.parked[i].second == g_device) {
+            if (g_streams.parked[i].second == t_device) {
                 *out = g_streams.parked[i].first;
                 g_streams.parked.erase(g_streams.parked.begin() + (long)i);
                 return hipSuccess;
@@ -175,7 +187,7 @@ void stream_park(hipStream_t s) {
     if (!s) return;
     {
         std::lock_guard<std::mutex> lk(g_streams.mu);
-        if (g_streams.parked.size() < 64 && g_device >= 0) { g_streams.parked.emplace_back(s, g_device); return; }
+        if (g_streams.parked.size() < 256 && t_device >= 0) { g_streams.parked.emplace_back(s, t_device); return; }
     }
     (void)hipStreamDestroy(s);
 }
@@ -207,6 +219,7 @@ struct PhaseTrace {
 } // namespace
 
 struct dpx_batch {
+    int device = -1; /* the device the batch lives on */
     dpx_params prm{};
     unsigned flags = 0;
     size_t numPairs = 0;
@@ -230,6 +243,8 @@ struct dpx_batch {
     hipStream_t stream = nullptr;     /* the batch's own stream */
     hipStream_t sideStream = nullptr; /* secondary kernels of a fill run here, concurrently with the main one (launch_all) */
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evT0 = nullptr, evT1 = nullptr; /* DPX_TIME_FILLS: recorded around every dpx_batch_fill() */
+    bool fillTimed = false;
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
     size_t ldsBytes = 0;
@@ -242,16 +257,20 @@ struct dpx_batch {
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
     size_t pkLdsBytes = 0;
-    /* traceback (lazy): device line buffers + host mirror */
+    /* result text (lazy): device line buffers of k_traceback, the packed blocks built from them, pinned host mirrors */
     uint64_t *dTbOff = nullptr;
     char *dTb = nullptr;
     int32_t *dTbLen = nullptr;
+    uint64_t *dOutOff = nullptr, *dOutScratch = nullptr; /* per-pair byte offsets of the blocks (+ total), scan scratch */
+    char *dOut = nullptr;
     std::vector<uint64_t> tbOff;
-    char *hTb = nullptr;   /* pinned host mirror of the line buffers (pageable D2H of ~70 MB costs 3-4x more) */
-    size_t hTbBytes = 0;   /* bytes of line data */
-    size_t dTbCap = 0, hTbCap = 0; /* capacities of the (possibly recycled) buffers */
-    std::vector<int32_t> hTbLen;
-    bool tbValid = false;
+    char *hMeta = nullptr; /* pinned: uint64 offsets[numPairs + 1], then int32 alignment lengths[numPairs] */
+    char *hOut = nullptr;  /* pinned: the packed text */
+    size_t hOutBytes = 0;
+    size_t dTbCap = 0, dOutCap = 0, hMetaCap = 0, hOutCap = 0; /* capacities of the (possibly recycled) buffers */
+    bool tbLinesValid = false; /* k_traceback has run since the last fill */
+    int outState = 0;          /* 0 none, 1 dpx_batch_output_begin() in flight, 2 text on the host */
+    uint64_t outFirst = 0;     /* pair number of the batch's first pair in the text */
     size_t nSingles = 0, nCouples = 0, nLanePairs = 0, nWaves = 0; /* launch-list sizes (dpx_batch_describe) */
 };
 
@@ -297,7 +316,26 @@ int dpx_init(int device) {
     if (device < 0 || device >= n) return DPX_ERR_INVALID;
     e = hipSetDevice(device);
     if (e != hipSuccess) { hip_fail(e, "hipSetDevice"); return DPX_ERR_NO_DEVICE; }
+    const bool first = g_device != device;
     g_device = device;
+    t_device = device;
+    if (first) {
+        /* One-time costs of the HIP runtime belong to device initialisation (the reference's mains likewise create their
+         * context and query the device before they start their timer, cuda/LNW/LinearNeedlemanWunschV19.cu:357-409):
+         * the first hipStreamCreate costs ~9 ms, the first pageable H2D / D2H another ~9 ms (runtime staging buffers).
+         * Two streams go to the stream cache, and a small copy runs in each direction. */
+        hipStream_t s0 = nullptr, s1 = nullptr;
+        if (hipStreamCreateWithFlags(&s0, hipStreamNonBlocking) == hipSuccess) stream_park(s0);
+        if (hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess) stream_park(s1);
+        void *d = nullptr;
+        std::vector<char> h((size_t)1 << 20, 0);
+        if (hipMalloc(&d, h.size()) == hipSuccess) {
+            (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+    }
     return DPX_OK;
 }
 
@@ -305,7 +343,7 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    HIP_TRY(hipGetDeviceProperties(&prop, t_device));
     if (name && nameCap) { snprintf(name, nameCap, "%s (%s)", prop.name, prop.gcnArchName); }
     if (computeUnits) *computeUnits = prop.multiProcessorCount;
     if (hbmBytes) *hbmBytes = prop.totalGlobalMem;
@@ -382,35 +420,42 @@ static int lanes_rows(int maxM, int algo) { return (maxM <= 512 || algo == DPX_A
  * length (the wave runs max(n + lanes) steps) and the lanes fill up: 100k short reads (queries 80-130) reach 94 % lane
  * occupancy.  Returns the reference area in bytes; `idx` comes back in slot order (= matrix placement order). */
 static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int32_t> &idx, int R, int maxN, std::vector<dpx_wave_desc> &waves) {
-    struct Bin { dpx_wave_desc d; int lanes = 0, slots = 0; size_t ref = 0; };
+    struct Bin { dpx_wave_desc d; int lanes = 0, slots = 0; size_t ref = 0; bool closed = false; };
     const size_t refCap = std::max<size_t>(1024, align_up((size_t)maxN + 31, 16));
-    constexpr size_t kWindow = 256;
-    std::vector<Bin> open;
-    std::vector<int32_t> order;
-    order.reserve(idx.size());
-    size_t area = 0;
-    auto emit = [&](const Bin &bn) {
-        waves.push_back(bn.d);
-        for (int k = 0; k < bn.slots; k++) order.push_back(bn.d.pair[k]);
-        area = std::max(area, bn.ref);
-    };
+    constexpr size_t kWindow = 256; /* open waves: pairs arrive sorted by reference length, so a window keeps a wave's pairs alike */
+    std::vector<Bin> bins;          /* in opening order = emission order */
+    std::vector<int32_t> byFree[65]; /* open bins by free lanes (entries go stale when a bin moves on: checked on use) */
+    size_t oldestOpen = 0, numOpen = 0;
+    bins.reserve(idx.size() / 3 + 8);
     for (int32_t i : idx) {
         const dpx_pair_dev &pd = pairs[i];
         const int L = (pd.m + R - 1) / R;
         const size_t need = align_up((size_t)pd.n + 31, 16);
         int best = -1;
-        for (size_t k = 0; k < open.size(); k++) {
-            const Bin &bn = open[k];
-            if (bn.lanes + L > 64 || bn.slots >= DPX_WAVE_SLOTS || bn.ref + need > refCap) continue;
-            if (best < 0 || bn.lanes > open[best].lanes) best = (int)k; /* tightest fit */
+        for (int f = L; f <= 64 && best < 0; f++) { /* tightest fit first */
+            std::vector<int32_t> &lst = byFree[f];
+            while (!lst.empty()) {
+                const int32_t k = lst.back();
+                const Bin &bn = bins[k];
+                if (bn.closed || 64 - bn.lanes != f) { lst.pop_back(); continue; } /* stale entry */
+                if (bn.slots >= DPX_WAVE_SLOTS || bn.ref + need > refCap) break;   /* this bucket's newest bin is full in another way */
+                best = k;
+                lst.pop_back();
+                break;
+            }
         }
         if (best < 0) {
-            if (open.size() >= kWindow) { emit(open.front()); open.erase(open.begin()); }
-            open.emplace_back();
-            memset(&open.back().d, 0, sizeof(dpx_wave_desc));
-            best = (int)open.size() - 1;
+            if (numOpen >= kWindow) { /* retire the oldest open wave */
+                while (bins[oldestOpen].closed) oldestOpen++;
+                bins[oldestOpen].closed = true;
+                numOpen--;
+            }
+            bins.emplace_back();
+            memset(&bins.back().d, 0, sizeof(dpx_wave_desc));
+            best = (int)bins.size() - 1;
+            numOpen++;
         }
-        Bin &bn = open[best];
+        Bin &bn = bins[best];
         bn.d.pair[bn.slots] = i;
         bn.d.first[bn.slots] = (uint8_t)bn.lanes;
         bn.d.num[bn.slots] = (uint8_t)L;
@@ -418,8 +463,18 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
         bn.lanes += L;
         bn.slots++;
         bn.ref += need;
+        if (bn.lanes < 64 && bn.slots < DPX_WAVE_SLOTS) byFree[64 - bn.lanes].push_back(best);
+        else { bn.closed = true; numOpen--; }
     }
-    for (const Bin &bn : open) emit(bn);
+    std::vector<int32_t> order;
+    order.reserve(idx.size());
+    size_t area = 0;
+    waves.reserve(bins.size());
+    for (const Bin &bn : bins) {
+        waves.push_back(bn.d);
+        for (int k = 0; k < bn.slots; k++) order.push_back(bn.d.pair[k]);
+        area = std::max(area, bn.ref);
+    }
     idx.swap(order);
     return area;
 }
@@ -438,17 +493,21 @@ static uint64_t band_cells(long long m, long long n, long long B) {
 int dpx_batch_destroy(dpx_batch *b) {
     if (!b) return DPX_OK;
     PhaseTrace trace;
-    if (g_device >= 0) (void)hipSetDevice(g_device);
+    if (b->device >= 0) { (void)hipSetDevice(b->device); t_device = b->device; }
     /* buffers are parked for the next batch, not freed: nothing of this batch may still be running on them */
     if (b->lastStream && b->lastStream != b->stream) (void)hipStreamSynchronize(b->lastStream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); stream_park(b->stream); }
     if (b->sideStream) { (void)hipStreamSynchronize(b->sideStream); stream_park(b->sideStream); }
+    if (b->evT0) (void)hipEventDestroy(b->evT0);
+    if (b->evT1) (void)hipEventDestroy(b->evT1);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     if (b->evJoin) (void)hipEventDestroy(b->evJoin);
     g_arenaCache.park(b->arena, b->arenaCap);
     g_matCache.park(b->dMat, b->matPoolBytes);
     g_tbDevCache.park(b->dTb, b->dTbCap);
-    g_tbHostCache.park(b->hTb, b->hTbCap);
+    g_tbDevCache.park(b->dOut, b->dOutCap);
+    g_tbHostCache.park(b->hMeta, b->hMetaCap);
+    g_tbHostCache.park(b->hOut, b->hOutCap);
     delete b;
     trace.mark("destroy");
     return DPX_OK;
@@ -456,17 +515,28 @@ int dpx_batch_destroy(dpx_batch *b) {
 
 int dpx_batch_create(const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
                      size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
+    return dpx_batch_create_on(-1, params, sequences, numBytes, pairs, firstPair, numPairs, flags, out);
+}
+
+int dpx_batch_create_on(int device, const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
+                        size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
     if (!out) return DPX_ERR_INVALID;
     *out = nullptr;
     int rc = validate_params(params);
     if (rc != DPX_OK) return rc;
     if ((numPairs && (!pairs || !sequences)) || numPairs > 0x7fffffffu) return DPX_ERR_INVALID;
-    rc = bind_device();
+    if (device >= 0) { /* an explicit device: must exist (-1 = the default device of dpx_init) */
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DPX_ERR_NO_DEVICE; }
+        if (device >= n) return DPX_ERR_INVALID;
+    } else if (device != -1) return DPX_ERR_INVALID;
+    rc = bind_device(device);
     if (rc != DPX_OK) return rc;
 
     PhaseTrace trace;
     dpx_batch *b = new (std::nothrow) dpx_batch();
     if (!b) return DPX_ERR_NOMEM;
+    b->device = t_device;
     b->prm = *params;
     b->flags = flags;
     b->numPairs = numPairs;
@@ -581,12 +651,19 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
             if (pd.m > 0 && pd.n > 0) { couples.push_back((int32_t)i); pd.lanes = 16; pd.rows = kLanesR; }
             else singles.push_back((int32_t)i);
         }
-        /* a wave runs max(n + lanes) steps: neighbours of similar reference length, longest first */
-        std::stable_sort(couples.begin(), couples.end(), [&](int32_t x, int32_t y) {
-            const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
-            if (X.n != Y.n) return X.n > Y.n;
-            return X.m > Y.m;
-        });
+        /* a wave runs max(n + lanes) steps: neighbours of similar reference length, longest first (then longest query first).
+         * Both keys are small integers: two stable counting passes instead of a comparison sort (12 ms per 100k pairs) */
+        {
+            std::vector<int32_t> tmp(couples.size());
+            auto pass = [&](const std::vector<int32_t> &in, std::vector<int32_t> &out, int maxKey, auto key) {
+                std::vector<uint32_t> cnt((size_t)maxKey + 2, 0);
+                for (int32_t c : in) cnt[(size_t)(maxKey - key(c)) + 1]++; /* descending */
+                for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+                for (int32_t c : in) out[cnt[(size_t)(maxKey - key(c))]++] = c;
+            };
+            pass(couples, tmp, b->maxM, [&](int32_t c) { return b->pairs[c].m; });
+            pass(tmp, couples, b->maxN, [&](int32_t c) { return b->pairs[c].n; });
+        }
         lanesPairs = couples.size();
         b->quad = !couples.empty();
         if (b->quad) lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
@@ -654,7 +731,8 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
         const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
         const size_t szCouples = std::max(szI32, align_up(waves.size() * sizeof(dpx_wave_desc), 256)); /* couples, or the wave descriptors */
-        const size_t need = szSeq + szPairs + 5 * szI32 + szCouples + szOff; /* score, endRow, endCol, order, couples, tbLen */
+        const size_t szScan = align_up((dpx_out_scan_tiles(np1) + 1) * sizeof(uint64_t), 256);
+        const size_t need = szSeq + szPairs + 5 * szI32 + szCouples + 2 * szOff + szScan; /* score, endRow, endCol, order, couples, tbLen; tbOff, outOff, scan */
         CREATE_TRY(g_arenaCache.take((void **)&b->arena, need, &b->arenaCap));
         char *q = b->arena;
         b->dSeq = q;                  q += szSeq;
@@ -665,7 +743,9 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         b->dOrder = nullptr;          arenaOrder = (int32_t *)q; q += szI32;
         b->dCouples = nullptr;        arenaCouples = (int32_t *)q; q += szCouples;
         b->dTbLen = (int32_t *)q;     q += szI32;
-        b->dTbOff = (uint64_t *)q;
+        b->dTbOff = (uint64_t *)q;    q += szOff;
+        b->dOutOff = (uint64_t *)q;   q += szOff;
+        b->dOutScratch = (uint64_t *)q;
     }
     trace.mark("create: arena");
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
@@ -701,7 +781,7 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
         if (want) {
             hipDeviceProp_t prop;
             int cus = 256;
-            if (hipGetDeviceProperties(&prop, g_device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            if (hipGetDeviceProperties(&prop, t_device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
             /* One stream per wave slot.  Whole workgroups per CU (the dispatcher deals workgroups round-robin, so CU j gets
              * blocks j, j+CUs, ...): numStreams = CUs * 4 waves * k workgroups, k <= 4 (the LDS request caps residency at
              * 4 workgroups per CU).  A ragged multiple (e.g. 3.26 workgroups per CU) measured 24 % slower: the CUs
@@ -780,6 +860,14 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     }
     trace.mark("create: launch lists+placement");
     if (numPairs) CREATE_TRY(hipMemcpy(b->dPairs, b->pairs.data(), numPairs * sizeof(dpx_pair_dev), hipMemcpyHostToDevice));
+    if (b->store) { /* where k_traceback puts a pair's three lines (each with a dword-aligned capacity of m + n + 1): needed by the
+                       output path, uploaded here so that dpx_batch_output_begin() never has to wait for the host */
+        b->tbOff.resize(numPairs + 1);
+        uint64_t off = 0;
+        for (size_t i = 0; i < numPairs; i++) { b->tbOff[i] = off; off += 3ull * (uint64_t)((b->pairs[i].m + b->pairs[i].n + 1 + 3) & ~3); }
+        b->tbOff[numPairs] = off;
+        CREATE_TRY(hipMemcpy(b->dTbOff, b->tbOff.data(), (numPairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     if (b->store && b->matElems) {
         void *pool = nullptr;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
@@ -894,19 +982,39 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
 
 int dpx_batch_fill(dpx_batch *b, void *stream) {
     if (!b) return DPX_ERR_INVALID;
-    int rc = bind_device();
+    int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    const bool timed = (b->flags & DPX_TIME_FILLS) != 0;
+    if (timed) {
+        if (!b->evT0) HIP_TRY(hipEventCreate(&b->evT0));
+        if (!b->evT1) HIP_TRY(hipEventCreate(&b->evT1));
+        HIP_TRY(hipEventRecord(b->evT0, s));
+    }
     HIP_TRY(launch_all(b, s));
+    if (timed) { HIP_TRY(hipEventRecord(b->evT1, s)); b->fillTimed = true; }
     b->lastStream = s;
     b->filled = true;
-    b->tbValid = false;
+    b->tbLinesValid = false;
+    b->outState = 0;
+    return DPX_OK;
+}
+
+int dpx_batch_last_fill_usec(dpx_batch *b, double *usec) {
+    if (!b || !usec) return DPX_ERR_INVALID;
+    if (!b->fillTimed) return DPX_ERR_NOT_FILLED; /* no fill yet, or the batch was created without DPX_TIME_FILLS */
+    int rc = bind_device(b->device);
+    if (rc != DPX_OK) return rc;
+    HIP_TRY(hipEventSynchronize(b->evT1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->evT0, b->evT1));
+    *usec = (double)ms * 1000.0;
     return DPX_OK;
 }
 
 int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     if (!b || repeats < 1 || !usecPerFill) return DPX_ERR_INVALID;
-    int rc = bind_device();
+    int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
@@ -923,13 +1031,14 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     *usecPerFill = (double)ms * 1000.0 / repeats;
     b->lastStream = b->stream;
     b->filled = true;
-    b->tbValid = false;
+    b->tbLinesValid = false;
+    b->outState = 0;
     return DPX_OK;
 }
 
 int dpx_batch_sync(dpx_batch *b) {
     if (!b) return DPX_ERR_INVALID;
-    int rc = bind_device();
+    int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -947,7 +1056,7 @@ int dpx_batch_device_results(dpx_batch *b, void **dScores, void **dEndRow, void 
 int dpx_batch_results(dpx_batch *b, int32_t *scores, int32_t *endRow, int32_t *endCol) {
     if (!b) return DPX_ERR_INVALID;
     if (!b->filled) return DPX_ERR_NOT_FILLED;
-    int rc = bind_device();
+    int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -964,7 +1073,7 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     if (!b || !out || pair >= b->numPairs || which < 0 || which >= b->planes) return DPX_ERR_INVALID;
     if (!b->store) return DPX_ERR_NO_MATRIX;
     if (!b->filled) return DPX_ERR_NOT_FILLED;
-    int rc = bind_device();
+    int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     const dpx_pair_dev &pd = b->pairs[pair];
     const size_t total = (size_t)(pd.m + 1) * (size_t)(pd.n + 1);
@@ -981,36 +1090,128 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
     return DPX_OK;
 }
 
-/* Run the traceback kernel for every pair of the batch and mirror the lines on the host (once per fill). */
-static int run_traceback(dpx_batch *b) {
-    if (b->tbValid) return DPX_OK;
+/* ---- result text: device traceback -> per-pair block lengths -> exclusive scan -> packed blocks -> D2H of the real bytes ----
+ * (the reference's V15 packed variable-length strings, cuda/LNW/LinearNeedlemanWunschV15.cu:168-172,372-425; the blocks are
+ * already formatted as c++/main.cpp prints them, so a driver writes a batch with one fwrite) */
+
+/* stage 1, asynchronous on the batch's stream: kernels + D2H of the offsets / lengths */
+static int output_begin(dpx_batch *b, uint64_t firstNumber) {
+    PhaseTrace trace;
     const size_t np = b->numPairs;
-    if (b->tbOff.empty() || !b->dTb || !b->hTb) { /* (a failed earlier attempt leaves tbOff empty: set up again) */
-        std::vector<uint64_t> offs(np + 1);
-        uint64_t off = 0;
-        /* three lines per pair, each with a dword-aligned capacity of m + n + 1 (the kernel writes aligned dwords) */
-        for (size_t i = 0; i < np; i++) { offs[i] = off; off += 3ull * (uint64_t)((b->pairs[i].m + b->pairs[i].n + 1 + 3) & ~3); }
-        offs[np] = off;
-        const size_t need = (size_t)std::max<uint64_t>(off, 16);
-        if (!b->dTb) HIP_TRY(g_tbDevCache.take((void **)&b->dTb, need, &b->dTbCap));
-        HIP_TRY(hipMemcpy(b->dTbOff, offs.data(), (np + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        if (!b->hTb) HIP_TRY(g_tbHostCache.take((void **)&b->hTb, need, &b->hTbCap));
-        b->hTbBytes = off;
-        b->hTbLen.resize(np);
-        b->tbOff.swap(offs); /* only now: every buffer the later calls rely on exists */
+    if (b->outState == 2 && b->outFirst == firstNumber) return DPX_OK; /* already on the host */
+    if (b->outState == 1 && b->outFirst == firstNumber) return DPX_OK; /* already in flight */
+    if (b->outState == 1) HIP_TRY(hipStreamSynchronize(b->stream));    /* a run with another numbering is in flight: let it finish */
+    if (!b->dTb || !b->dOut || !b->hMeta) { /* buffers of the output path, on first use (a failed attempt is simply repeated) */
+        const uint64_t lines = b->tbOff[np];
+        if (!b->dTb) HIP_TRY(g_tbDevCache.take((void **)&b->dTb, (size_t)std::max<uint64_t>(lines, 16), &b->dTbCap));
+        /* packed text, worst case: every alignment m + n long, 20 digits of pair number, 11 of score */
+        if (!b->dOut) HIP_TRY(g_tbDevCache.take((void **)&b->dOut, (size_t)(lines + 40ull * np + 16), &b->dOutCap));
+        if (!b->hMeta) HIP_TRY(g_tbHostCache.take((void **)&b->hMeta, (np + 1) * sizeof(uint64_t) + np * sizeof(int32_t) + 16, &b->hMetaCap));
+        trace.mark("output: buffers");
     }
+    uint64_t *hOff = reinterpret_cast<uint64_t *>(b->hMeta);
+    int32_t *hLen = reinterpret_cast<int32_t *>(hOff + np + 1);
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
-    /* enough lanes in flight to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster) */
-    bool cachedWalk = b->numPairs >= 65536;
-    if (const char *env = getenv("DPX_TB_CACHED")) cachedWalk = atoi(env) != 0; /* tests force either walk */
-    HIP_TRY(dpx_launch_traceback(b->args, (int)b->numPairs, b->kernelAlgo, b->R, b->planes, cachedWalk, b->dTbOff, b->dTb, b->dTbLen,
-                                 b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    if (np) {
-        HIP_TRY(hipMemcpy(b->hTb, b->dTb, b->hTbBytes, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(b->hTbLen.data(), b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (!b->tbLinesValid) {
+        /* enough lanes in flight to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster) */
+        bool cachedWalk = b->numPairs >= 65536;
+        if (const char *env = getenv("DPX_TB_CACHED")) cachedWalk = atoi(env) != 0; /* tests force either walk */
+        HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, cachedWalk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
+        b->tbLinesValid = true;
     }
-    b->tbValid = true;
+    HIP_TRY(dpx_launch_output(b->dPairs, b->dScore, b->dTbLen, b->dTbOff, b->dTb, (int)np, (unsigned long long)firstNumber,
+                              reinterpret_cast<unsigned long long *>(b->dOutScratch), reinterpret_cast<unsigned long long *>(b->dOutOff), b->dOut,
+                              false, false, b->stream));
+    if (np) {
+        HIP_TRY(hipMemcpyAsync(hOff, b->dOutOff, (np + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(hLen, b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    } else {
+        hOff[0] = 0;
+    }
+    b->outState = 1;
+    b->outFirst = firstNumber;
+    trace.mark("output: launches");
+    return DPX_OK;
+}
+
+/* stage 2: wait, then copy exactly the bytes the blocks occupy */
+static int output_end(dpx_batch *b) {
+    if (b->outState == 2) return DPX_OK;
+    if (b->outState != 1) return DPX_ERR_INVALID;
+    PhaseTrace trace;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    trace.mark("output: wait for device");
+    const uint64_t total = reinterpret_cast<const uint64_t *>(b->hMeta)[b->numPairs];
+    if (!b->hOut || b->hOutCap < total + 1) {
+        g_tbHostCache.park(b->hOut, b->hOutCap);
+        b->hOut = nullptr;
+        HIP_TRY(g_tbHostCache.take((void **)&b->hOut, (size_t)total + 1, &b->hOutCap));
+        trace.mark("output: pinned text buffer");
+    }
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(b->hOut, b->dOut, (size_t)total, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    b->hOut[total] = 0;
+    b->hOutBytes = (size_t)total;
+    b->outState = 2;
+    trace.mark("output: D2H text");
+    return DPX_OK;
+}
+
+int dpx_batch_output_begin(dpx_batch *b, uint64_t firstPairNumber) {
+    if (!b) return DPX_ERR_INVALID;
+    if (!b->store) return DPX_ERR_NO_MATRIX;
+    if (!b->filled) return DPX_ERR_NOT_FILLED;
+    int rc = bind_device(b->device);
+    if (rc != DPX_OK) return rc;
+    return output_begin(b, firstPairNumber);
+}
+
+int dpx_batch_output_end(dpx_batch *b, const char **text, size_t *bytes, const uint64_t **offsets) {
+    if (!b) return DPX_ERR_INVALID;
+    if (b->outState == 0) return DPX_ERR_NOT_FILLED; /* no dpx_batch_output_begin() since the last fill */
+    int rc = bind_device(b->device);
+    if (rc != DPX_OK) return rc;
+    rc = output_end(b);
+    if (rc != DPX_OK) return rc;
+    if (text) *text = b->hOut;
+    if (bytes) *bytes = b->hOutBytes;
+    if (offsets) *offsets = reinterpret_cast<const uint64_t *>(b->hMeta);
+    return DPX_OK;
+}
+
+/* pinned text buffers handed to the caller by dpx_batch_output_take(): pointer -> capacity, for dpx_text_free() */
+namespace { struct Taken { void *ptr; size_t cap; int device; }; std::mutex g_takenMu; std::vector<Taken> g_taken; }
+
+int dpx_batch_output_take(dpx_batch *b, char **text, size_t *bytes) {
+    if (!b || !text) return DPX_ERR_INVALID;
+    if (b->outState == 0) return DPX_ERR_NOT_FILLED;
+    int rc = bind_device(b->device);
+    if (rc != DPX_OK) return rc;
+    rc = output_end(b);
+    if (rc != DPX_OK) return rc;
+    { std::lock_guard<std::mutex> lk(g_takenMu); g_taken.push_back(Taken{(void *)b->hOut, b->hOutCap, b->device}); }
+    *text = b->hOut;
+    if (bytes) *bytes = b->hOutBytes;
+    b->hOut = nullptr; /* the batch no longer owns it; a later dpx_batch_traceback() / _output_end() rebuilds the text */
+    b->hOutCap = 0;
+    b->outState = 0;
+    return DPX_OK;
+}
+
+int dpx_text_free(char *text) {
+    if (!text) return DPX_OK;
+    size_t cap = 0;
+    int dev = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_takenMu);
+        for (size_t i = 0; i < g_taken.size(); i++)
+            if (g_taken[i].ptr == (void *)text) { cap = g_taken[i].cap; dev = g_taken[i].device; g_taken.erase(g_taken.begin() + (long)i); break; }
+    }
+    if (!cap) return DPX_ERR_INVALID; /* not a buffer dpx_batch_output_take() handed out */
+    if (dev >= 0) { (void)hipSetDevice(dev); t_device = dev; }
+    g_tbHostCache.park(text, cap);
     return DPX_OK;
 }
 
@@ -1018,18 +1219,21 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
     if (!b || pair >= b->numPairs) return DPX_ERR_INVALID;
     if (!b->store) return DPX_ERR_NO_MATRIX;
     if (!b->filled) return DPX_ERR_NOT_FILLED;
-    if (!b->tbValid) { /* first call after a fill walks every pair of the batch on the device; later calls only copy lines */
-        int rc = bind_device();
+    if (b->outState != 2) { /* first call after a fill walks every pair of the batch on the device; later calls only copy lines */
+        int rc = bind_device(b->device);
         if (rc != DPX_OK) return rc;
-        rc = run_traceback(b);
+        rc = output_begin(b, b->outState == 1 ? b->outFirst : 0);
+        if (rc == DPX_OK) rc = output_end(b);
         if (rc != DPX_OK) return rc;
     }
-    const int cap = (b->pairs[pair].m + b->pairs[pair].n + 1 + 3) & ~3;
-    const int k = b->hTbLen[pair];
-    const char *base = b->hTb + b->tbOff[pair];
+    const uint64_t *hOff = reinterpret_cast<const uint64_t *>(b->hMeta);
+    const int32_t *hLen = reinterpret_cast<const int32_t *>(hOff + b->numPairs + 1);
+    const int k = hLen[pair];
+    /* the pair's block ends with its three lines, each k characters + '\n' */
+    const char *lines = b->hOut + hOff[pair + 1] - 3 * (size_t)(k + 1);
     char *dst[3] = {refLine, relLine, qryLine};
     for (int l = 0; l < 3; l++)
-        if (dst[l]) { memcpy(dst[l], base + (size_t)l * cap + (cap - k), (size_t)k); dst[l][k] = 0; }
+        if (dst[l]) { memcpy(dst[l], lines + (size_t)l * (size_t)(k + 1), (size_t)k); dst[l][k] = 0; }
     if (len) *len = k;
     return DPX_OK;
 }

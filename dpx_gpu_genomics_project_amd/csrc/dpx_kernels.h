@@ -51,6 +51,10 @@ hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int alg
  * be bound by sector requests rather than by load latency) */
 hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, bool cachedWalk,
                                 const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream);
+size_t dpx_out_scan_tiles(size_t numPairs);
+hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff, const char *tb,
+                             int numPairs, unsigned long long firstNumber, unsigned long long *tileSums, unsigned long long *outOff, char *out,
+                             bool scanOnly, bool compactOnly, hipStream_t stream);
 hipError_t dpx_launch_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
                                 uint32_t *res, uint32_t *pred, hipStream_t stream);
 

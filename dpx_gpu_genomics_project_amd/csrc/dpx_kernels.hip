@@ -1809,6 +1809,120 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
 }
 
 /* =====================================================================================================
+ * Output path: packed, variable-length result text built on the device -- the reference's V15 idea
+ * (cuda/LNW/LinearNeedlemanWunschV15.cu:168-172,372-425: per-pair string lengths, prefix offsets, one packed buffer, one
+ * D2H of the real bytes) taken one step further: the device writes each pair's block exactly as c++/main.cpp prints it,
+ *     "<pair number> | <score>\n<reference line>\n<relation line>\n<query line>\n"
+ * (three empty lines for a zero-score local alignment, c++/LinearSmithWaterman.cpp:253-257), so the host's share of the
+ * output is one fwrite per batch.  Three small kernels after k_traceback: block lengths, an exclusive scan, the copy.
+ * ===================================================================================================== */
+__device__ __forceinline__ int dec_digits(unsigned long long v) {
+    int d = 1;
+    while (v >= 10ull) { v /= 10ull; d++; }
+    return d;
+}
+__device__ __forceinline__ unsigned long long block_len(unsigned long long number, int score, int len) {
+    const unsigned us = score < 0 ? 0u - (unsigned)score : (unsigned)score;
+    return (unsigned long long)(dec_digits(number) + 3 + (score < 0 ? 1 : 0) + dec_digits(us) + 1) + 3ull * (unsigned long long)(len + 1);
+}
+
+constexpr int kScanThreads = 256, kScanPerThread = 8, kScanTile = kScanThreads * kScanPerThread;
+
+/* inclusive scan of one value per thread across the workgroup; returns the exclusive prefix, *total = sum over the group */
+__device__ __forceinline__ unsigned long long group_exclusive(unsigned long long v, unsigned long long *lds, unsigned long long *total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(x, off, 64);
+        if (lane >= off) x += o;
+    }
+    if (lane == 63) lds[wv] = x;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+    for (int k = 0; k < kScanThreads / 64; k++) { const unsigned long long w = lds[k]; if (k < wv) base += w; all += w; }
+    __syncthreads();
+    *total = all;
+    return base + x - v;
+}
+
+/* phase 1: per-tile totals of the block lengths; phase 3 (FINAL): per-pair offsets = tile base + exclusive prefix */
+template <bool FINAL>
+__global__ void __launch_bounds__(kScanThreads) k_out_scan(const int32_t *score, const int32_t *tbLen, int numPairs, unsigned long long firstNumber,
+                                                           unsigned long long *tileSums, unsigned long long *outOff) {
+    __shared__ unsigned long long lds[kScanThreads / 64];
+    const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPerThread;
+    unsigned long long v[kScanPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        const size_t p = base + k;
+        v[k] = p < (size_t)numPairs ? block_len(firstNumber + p, score[p], tbLen[p]) : 0ull;
+        mine += v[k];
+    }
+    unsigned long long total;
+    unsigned long long ex = group_exclusive(mine, lds, &total);
+    if constexpr (!FINAL) {
+        if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+    } else {
+        ex += tileSums[blockIdx.x]; /* exclusive prefix of the tiles, from k_out_scan_tiles */
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) {
+            const size_t p = base + k;
+            if (p < (size_t)numPairs) outOff[p] = ex;
+            ex += v[k];
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanThreads - 1) outOff[numPairs] = ex; /* total bytes */
+    }
+}
+
+/* phase 2: exclusive scan of the tile totals, in place (one workgroup; numTiles is small: pairs / 2048) */
+__global__ void __launch_bounds__(kScanThreads) k_out_scan_tiles(unsigned long long *tileSums, int numTiles) {
+    __shared__ unsigned long long lds[kScanThreads / 64];
+    unsigned long long carry = 0;
+    for (int t0 = 0; t0 < numTiles; t0 += kScanThreads) {
+        const int t = t0 + (int)threadIdx.x;
+        const unsigned long long v = t < numTiles ? tileSums[t] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = group_exclusive(v, lds, &total);
+        if (t < numTiles) tileSums[t] = carry + ex;
+        carry += total;
+    }
+}
+
+/* one wave per pair: header by lane 0, the three right-aligned lines of k_traceback copied 64 bytes per instruction */
+__global__ void __launch_bounds__(256) k_out_compact(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff,
+                                                      const char *tb, int numPairs, unsigned long long firstNumber,
+                                                      const unsigned long long *outOff, char *out) {
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (p >= numPairs) return;
+    const int len = tbLen[p], sc = score[p];
+    const int cap = (pairs[p].m + pairs[p].n + 1 + 3) & ~3; /* line capacity, as in k_traceback */
+    char *dst = out + outOff[p];
+    const unsigned long long number = firstNumber + (unsigned long long)p;
+    const unsigned us = sc < 0 ? 0u - (unsigned)sc : (unsigned)sc;
+    const int dn = dec_digits(number), ds = dec_digits(us), neg = sc < 0 ? 1 : 0;
+    const int hdr = dn + 3 + neg + ds + 1;
+    if (lane == 0) {
+        unsigned long long v = number;
+        for (int k = dn - 1; k >= 0; k--) { dst[k] = (char)('0' + (int)(v % 10ull)); v /= 10ull; }
+        dst[dn] = ' '; dst[dn + 1] = '|'; dst[dn + 2] = ' ';
+        if (neg) dst[dn + 3] = '-';
+        unsigned u = us;
+        for (int k = ds - 1; k >= 0; k--) { dst[dn + 3 + neg + k] = (char)('0' + (int)(u % 10u)); u /= 10u; }
+        dst[hdr - 1] = '\n';
+    }
+    const char *src = tb + tbOff[p] + (cap - len);
+#pragma unroll
+    for (int line = 0; line < 3; line++) {
+        const char *s = src + (size_t)line * cap;
+        char *d = dst + hdr + (size_t)line * (len + 1);
+        for (int x = lane; x < len; x += 64) d[x] = s[x];
+        if (lane == 0) d[len] = '\n';
+    }
+}
+
+/* =====================================================================================================
  * DPX primitive probe (dpx_prim_eval): runs the CDNA4 mappings of dpx_prims.hpp on the device.
  * ===================================================================================================== */
 __global__ void k_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
@@ -2036,6 +2150,25 @@ hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, 
     if (numPairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,
                        cachedWalk ? 1 : 0, a.endRow, a.endCol, tbOff, tb, tbLen);
+    return hipGetLastError();
+}
+
+/* result text of a batch: lengths -> exclusive scan (tileSums: ceil(numPairs / 2048) + 1 entries of scratch) -> packed copy.
+ * outOff[numPairs] receives the total number of bytes. */
+size_t dpx_out_scan_tiles(size_t numPairs) { return (numPairs + kScanTile - 1) / kScanTile; }
+hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff, const char *tb,
+                             int numPairs, unsigned long long firstNumber, unsigned long long *tileSums, unsigned long long *outOff, char *out,
+                             bool scanOnly, bool compactOnly, hipStream_t stream) {
+    if (numPairs <= 0) return hipSuccess;
+    const int tiles = (int)dpx_out_scan_tiles((size_t)numPairs);
+    if (!compactOnly) {
+        hipLaunchKernelGGL(k_out_scan<false>, dim3(tiles), dim3(kScanThreads), 0, stream, score, tbLen, numPairs, firstNumber, tileSums, outOff);
+        hipLaunchKernelGGL(k_out_scan_tiles, dim3(1), dim3(kScanThreads), 0, stream, tileSums, tiles);
+        hipLaunchKernelGGL(k_out_scan<true>, dim3(tiles), dim3(kScanThreads), 0, stream, score, tbLen, numPairs, firstNumber, tileSums, outOff);
+    }
+    if (!scanOnly)
+        hipLaunchKernelGGL(k_out_compact, dim3((unsigned)((numPairs + 3) / 4)), dim3(256), 0, stream, pairs, score, tbLen, tbOff, tb, numPairs, firstNumber,
+                           outOff, out);
     return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ struct Request {
 
 // Run a group of requests (same algorithm and weights) as ONE device batch: one create / fill / results / traceback
 // round trip instead of one per pair.
-void runGroup(const std::vector<Request *> &grp, bool wantMatrices) {
+void runGroup(const std::vector<Request *> &grp, bool wantMatrices, int device) {
     std::string flat; // parseInput layout: reference '\0' query '\0' per pair
     std::vector<dpx_seq_pair> pairs(grp.size());
     size_t maxCap = 0;
@@ -54,8 +54,8 @@ void runGroup(const std::vector<Request *> &grp, bool wantMatrices) {
     const Request &first = *grp[0];
     dpx_params prm{first.algo, first.match, first.mismatch, first.gapOpen, first.gapExtend, first.band};
     dpx_batch *b = nullptr;
-    int rc = dpx_batch_create(&prm, flat.data(), flat.size(), pairs.data(), 0, grp.size(), DPX_KEEP_MATRICES, &b);
-    if (rc != DPX_OK) fail("dpx_batch_create", rc);
+    int rc = dpx_batch_create_on(device, &prm, flat.data(), flat.size(), pairs.data(), 0, grp.size(), DPX_KEEP_MATRICES, &b);
+    if (rc != DPX_OK) fail("dpx_batch_create_on", rc);
     if ((rc = dpx_batch_fill(b, nullptr)) != DPX_OK) fail("dpx_batch_fill", rc);
     std::vector<int32_t> score(grp.size()), er(grp.size()), ec(grp.size());
     if ((rc = dpx_batch_results(b, score.data(), er.data(), ec.data())) != DPX_OK) fail("dpx_batch_results", rc);
@@ -86,13 +86,27 @@ void runGroup(const std::vector<Request *> &grp, bool wantMatrices) {
 }
 
 // The reference's driver aligns one pair per call from 20 threads (c++/main.cpp:18-19,203).  A GPU round trip costs
-// ~0.2 ms whatever the number of pairs in it, so concurrent callers are combined: the first thread to arrive becomes the
-// leader, lets the others queue up for a moment, runs everybody's pairs as one device batch and hands the results
-// back.  Same results, same stdout; the per-pair cost drops by about the number of threads.
+// ~0.2 ms whatever the number of pairs in it, so concurrent callers are combined: a thread that finds a free device
+// becomes a leader, lets the others queue up for a moment, runs everybody's pairs as one device batch and hands the
+// results back.  Same results, same stdout; the per-pair cost drops by about the number of threads.
+// Several devices: up to one leader per visible GPU at a time, devices dealt round-robin -- the unchanged main.cpp then
+// keeps a whole node busy from ONE process (DPX_DEVICES=n limits the devices used; DPX_CLASS_LEADERS=n sets the number
+// of concurrent leaders independently, e.g. to rehearse the multi-device hand-over on a one-GPU box).
 std::mutex g_mu;
 std::condition_variable g_cv;
 std::vector<Request *> g_queue;
-bool g_leaderActive = false;
+int g_activeLeaders = 0, g_maxLeaders = 0, g_numDevices = 0;
+unsigned g_nextSlot = 0;
+
+void initDevices() { // under g_mu
+    if (g_maxLeaders) return;
+    int n = 0;
+    if (dpx_device_count(&n) != DPX_OK || n <= 0) fail("dpx_device_count", DPX_ERR_NO_DEVICE);
+    if (const char *env = getenv("DPX_DEVICES")) { const int v = atoi(env); if (v >= 1 && v < n) n = v; }
+    g_numDevices = n;
+    g_maxLeaders = n;
+    if (const char *env = getenv("DPX_CLASS_LEADERS")) { const int v = atoi(env); if (v >= 1 && v <= 64) g_maxLeaders = v; }
+}
 
 void gatherWindow(std::unique_lock<std::mutex> &lk) {
     // wait while callers keep arriving: stop after 40 us without a new request, 400 us in total at most
@@ -115,29 +129,36 @@ void gatherWindow(std::unique_lock<std::mutex> &lk) {
 void dpxAlignPair(int algo, const std::string &reference, const std::string &query, int match, int mismatch, int gapOpen,
                   int gapExtend, int band, bool wantMatrices, DpxPairResult &out) {
     Request rq{algo, match, mismatch, gapOpen, gapExtend, band, &reference, &query, &out};
-    if (wantMatrices) { // matrix dumps (PRINT_MATRIX builds, print_matrix()): one pair, its own batch
-        runGroup({&rq}, true);
+    if (wantMatrices) { // matrix dumps (PRINT_MATRIX builds, print_matrix()): one pair, its own batch, default device
+        runGroup({&rq}, true, -1);
         return;
     }
     std::unique_lock<std::mutex> lk(g_mu);
+    initDevices();
     g_queue.push_back(&rq);
-    for (;;) { // follower: sleep until a leader has served this request, or until there is no leader
-        if (rq.done) return;
-        if (!g_leaderActive) break;
-        g_cv.wait(lk);
+    for (;;) {
+        if (rq.done) return;                                          // a leader has served this request
+        if (g_activeLeaders >= g_maxLeaders || g_queue.empty()) {     // no free device, or this request is in a leader's hands
+            g_cv.wait(lk);
+            continue;
+        }
+        g_activeLeaders++; // become a leader on the next device
+        const int device = (int)(g_nextSlot++ % (unsigned)g_numDevices);
+        gatherWindow(lk);
+        // serve everything queued with the parameters of the oldest request (usually everything), then retire
+        std::vector<Request *> grp, rest;
+        if (!g_queue.empty()) {
+            const Request &head = *g_queue.front();
+            for (Request *r : g_queue) (r->sameParams(head) ? grp : rest).push_back(r);
+            g_queue.swap(rest);
+        }
+        lk.unlock();
+        if (!grp.empty()) runGroup(grp, false, device);
+        lk.lock();
+        for (Request *r : grp) r->done = true;
+        g_activeLeaders--;
+        g_cv.notify_all(); // served followers return; one of the others (if any) becomes the next leader
     }
-    g_leaderActive = true;
-    gatherWindow(lk);
-    // serve everything queued with this request's parameters (this request included), then retire
-    std::vector<Request *> grp, rest;
-    for (Request *r : g_queue) (r->sameParams(rq) ? grp : rest).push_back(r);
-    g_queue.swap(rest);
-    lk.unlock();
-    runGroup(grp, false);
-    lk.lock();
-    for (Request *r : grp) r->done = true;
-    g_leaderActive = false;
-    g_cv.notify_all(); // served followers return; one of the others (if any) becomes the next leader
 }
 
 void dpxPrintScoreMatrix(const std::string &reference, const std::string &query, const std::vector<short> &M) {

@@ -1,8 +1,11 @@
 // dpx_main.cpp -- batched GPU driver of the MI355X engine, shaped like the reference's CUDA mains
 // (cuda/LNW/LinearNeedlemanWunschV19.cu:357-680, cuda/LinearSmithWaterman.cu:172-435): parse the pairs file,
-// move sequences + seqPair[] to the device once, fill batch after batch, trace back on the device, and print
-// "<pair> | <score>" + three lines per pair in input order.  The host prints batch k-1 while the GPU works on
-// batch k (the software pipeline of V19.cu:546-579).  stdout keeps the reference's lines so logs stay diff-able.
+// fill batch after batch, trace back on the device, and print "<pair> | <score>" + three lines per pair in input order.
+// Two batches are in flight on two streams (the copy/compute overlap of cuda/LNW/LinearNeedlemanWunschV13.cu:414-495):
+// while the device fills batch k+1, batch k's traceback, packing and D2H run on the other stream and batch k-1 is
+// being written to stdout by the printer thread (the software pipeline of V19.cu:546-579).  The device formats every
+// pair's block itself (packed variable-length result strings, V15.cu:168-172,372-425), so printing a batch is one fwrite.
+// stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
 //            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch 10000] [-device 0] [-noprint] [-rank r -world w]
@@ -14,7 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <memory>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,29 +28,15 @@
 
 namespace {
 
-struct BatchOut { // one text arena per batch instead of three std::strings per pair (300k small allocations per 100k pairs)
-    size_t first = 0;
-    std::vector<int32_t> score, len;
-    std::vector<size_t> off; // lines of pair k: text[off[k] + l * (len[k] + 1)], l = 0 (reference), 1 (relation), 2 (query)
-    std::unique_ptr<char[]> text; // not a vector: no zero-fill of tens of MB that are overwritten anyway
-    size_t textCap = 0;
-};
-
 [[noreturn]] void die(const char *what, int rc) {
     printf("%s\nDPX ERROR: %s (%s)\n", what, dpx_strerror(rc), dpx_last_error());
     exit(1);
 }
 
-void print_batch(const BatchOut *o, bool local) {
-    for (size_t k = 0; k < o->score.size(); k++) {
-        if (local && o->score[k] == 0) printf("%zu | 0\n\n\n\n", o->first + k);
-        else {
-            const char *t = o->text.get() + o->off[k];
-            const size_t stride = (size_t)o->len[k] + 1;
-            printf("%zu | %d\n%s\n%s\n%s\n", o->first + k, o->score[k], t, t + stride, t + 2 * stride);
-        }
-    }
-}
+struct InFlight { // one batch between dpx_batch_create and dpx_batch_destroy
+    dpx_batch *b = nullptr;
+    size_t first = 0, count = 0;
+};
 
 } // namespace
 
@@ -86,7 +75,6 @@ int main(int argc, char *argv[]) {
     const int algo = algoName == "LNW" ? DPX_ALGO_LNW : algoName == "LSW" ? DPX_ALGO_LSW : algoName == "ANW" ? DPX_ALGO_ANW
                      : algoName == "BSW" ? DPX_ALGO_BSW : -1;
     if (algo < 0) { fprintf(stderr, "unknown -algo %s\n", algoName.c_str()); exit(EXIT_FAILURE); }
-    const bool local = algo == DPX_ALGO_LSW || algo == DPX_ALGO_BSW;
 
     printf("[Device Details]\n");
     int deviceCount = 0;
@@ -118,59 +106,56 @@ int main(int argc, char *argv[]) {
     const dpx_params prm{algo, match, mismatch, gapOpen, gapExtend, band};
     static_assert(sizeof(seqPair) == sizeof(dpx_seq_pair), "seqPair must stay layout-compatible with the C ABI");
 
+    // pipeline: [create + fill + output_begin] of batch k+1 is issued before batch k is waited for; the printer thread
+    // writes batch k-1 meanwhile from the text buffer it took over, so batch k-1 itself is destroyed (its matrix pool
+    // parked for batch k+1) as soon as its text is on the host.
     std::thread printer;
-    BatchOut outs[2]; // batch k is printed from one while batch k+1 is assembled in the other; buffers are reused
-    size_t batchNo = 0;
-    size_t shardCells = 0;
-    for (size_t i = shardLo; i < shardHi; i++) shardCells += (size_t)sequenceIdxs[i].referenceSize * (size_t)sequenceIdxs[i].querySize;
-    for (size_t first = shardLo; first < shardHi; first += batchSize) {
-        const size_t count = std::min(batchSize, shardHi - first);
+    char *printingText = nullptr;
+    InFlight filling; // issued to the device, not yet waited for
+    auto retire_printed = [&]() {
+        if (printer.joinable()) { const uint64_t t0 = get_time(); printer.join(); printing_time += get_time() - t0; }
+        if (printingText) { dpx_text_free(printingText); printingText = nullptr; }
+    };
+    auto finish = [&](InFlight &f) { // wait for batch f, account its kernel time, hand its text to the printer
         uint64_t t0 = get_time();
-        dpx_batch *b = nullptr;
-        rc = dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, count,
-                              DPX_KEEP_MATRICES, &b);
-        if (rc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", rc);
-        memalloc_time += get_time() - t0;
-
-        double usec = 0;
-        if ((rc = dpx_batch_fill_timed(b, 1, &usec)) != DPX_OK) die("KERNEL LAUNCH FAILED", rc);
-        kernel_time += (uint64_t)usec;
-
-        t0 = get_time();
-        BatchOut *out = &outs[batchNo++ & 1];
-        out->first = shardFirst + first; // global pair number of the batch's first pair
-        out->score.resize(count);
-        if ((rc = dpx_batch_results(b, out->score.data(), nullptr, nullptr)) != DPX_OK) die("FAILED TO COPY SCORES", rc);
+        char *text = nullptr;
+        size_t bytes = 0;
         if (print) {
-            out->len.resize(count);
-            out->off.resize(count);
-            size_t total = 0; // worst case: an alignment is at most m + n columns long
-            for (size_t k = 0; k < count; k++)
-                total += 3 * ((size_t)sequenceIdxs[first + k].referenceSize + (size_t)sequenceIdxs[first + k].querySize + 2);
-            if (out->textCap < total) { out->text.reset(new char[total]); out->textCap = total; }
-            size_t at = 0;
-            for (size_t k = 0; k < count; k++) {
-                const size_t cap = (size_t)sequenceIdxs[first + k].referenceSize + (size_t)sequenceIdxs[first + k].querySize + 2;
-                char *t = out->text.get() + at; // the three lines land back to back once the length is known
-                int32_t len = 0;
-                if ((rc = dpx_batch_traceback(b, k, t, t + cap, t + 2 * cap, &len)) != DPX_OK) die("TRACEBACK FAILED", rc);
-                const size_t stride = (size_t)len + 1;
-                if (stride != cap) { memmove(t + stride, t + cap, stride); memmove(t + 2 * stride, t + 2 * cap, stride); }
-                out->off[k] = at;
-                out->len[k] = len;
-                at += 3 * stride;
-            }
-        }
+            if ((rc = dpx_batch_output_take(f.b, &text, &bytes)) != DPX_OK) die("TRACEBACK FAILED", rc);
+        } else if ((rc = dpx_batch_sync(f.b)) != DPX_OK) die("KERNEL FAILED", rc);
+        double usec = 0;
+        if ((rc = dpx_batch_last_fill_usec(f.b, &usec)) != DPX_OK) die("KERNEL TIMING FAILED", rc);
+        kernel_time += (uint64_t)usec;
         backtracking_time += get_time() - t0;
         t0 = get_time();
-        dpx_batch_destroy(b);
+        dpx_batch_destroy(f.b);
+        f = InFlight{};
         memalloc_time += get_time() - t0;
-
-        // hand the finished batch to the printer; it prints while the next batch is created and filled
-        if (printer.joinable()) { t0 = get_time(); printer.join(); printing_time += get_time() - t0; }
-        if (print) printer = std::thread(print_batch, out, local);
+        retire_printed();
+        printingText = text;
+        if (print) printer = std::thread([text, bytes]() { fwrite(text, 1, bytes, stdout); });
+    };
+    size_t shardCells = 0;
+    for (size_t i = shardLo; i < shardHi; i++) shardCells += (size_t)sequenceIdxs[i].referenceSize * (size_t)sequenceIdxs[i].querySize;
+    fflush(stdout); // the printer thread writes with fwrite from here on
+    for (size_t first = shardLo; first < shardHi; first += batchSize) {
+        InFlight next;
+        next.first = first;
+        next.count = std::min(batchSize, shardHi - first);
+        uint64_t t0 = get_time();
+        rc = dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
+                              DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
+        if (rc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", rc);
+        memalloc_time += get_time() - t0;
+        if ((rc = dpx_batch_fill(next.b, nullptr)) != DPX_OK) die("KERNEL LAUNCH FAILED", rc);
+        // global pair numbers: shardFirst + index inside the shard
+        if (print && (rc = dpx_batch_output_begin(next.b, shardFirst + first)) != DPX_OK) die("TRACEBACK LAUNCH FAILED", rc);
+        if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
+        filling = next;
     }
-    if (printer.joinable()) { uint64_t t0 = get_time(); printer.join(); printing_time += get_time() - t0; }
+    if (filling.b) finish(filling);
+    retire_printed();
+    fflush(stdout);
 
     const uint64_t elapsed_time = get_elapsed_time();
     printf("Elapsed time (usec): %llu\n", (unsigned long long)elapsed_time);

@@ -68,6 +68,7 @@ typedef struct dpx_params {
 /* dpx_batch_create flags */
 #define DPX_KEEP_MATRICES 0x0u /* default: write the int16 score matrices (H; H,I,D for ANW) to HBM */
 #define DPX_SCORE_ONLY    0x1u /* no matrix writeback (not HBM-bound; never used for the roofline figure) */
+#define DPX_TIME_FILLS    0x2u /* bracket every dpx_batch_fill() with HIP events: dpx_batch_last_fill_usec() */
 
 /* matrix selectors for dpx_batch_matrix */
 #define DPX_MAT_H 0 /* scoring matrix   (reference: memo / scoringMemo)            */
@@ -99,6 +100,14 @@ int dpx_abi_version(void);
 int dpx_batch_create(const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
                      size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
 
+/* The same on an explicit device (0 .. dpx_device_count()-1; -1 = the default device): one host process can drive
+ * several GPUs, each batch lives on the device it was created on and every call on it runs there.  The class surface
+ * uses this to spread the batches it forms from the reference's 20 threads over all visible devices (hostcpp/DpxPair.cpp),
+ * so the unchanged c++/main.cpp uses a whole node; one process per GPU (dpx_init(rank)) remains the layout of the
+ * batched driver and of bench.py.  device >= count is DPX_ERR_INVALID. */
+int dpx_batch_create_on(int device, const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
+                        size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
+
 /* Launch the DP fill for every pair of the batch on `stream` (a hipStream_t, or NULL for the batch's own
  * stream).  Asynchronous.  Replaces `needleman_wunsch_kernel<<<BATCH/2,32,smem>>>` (V19.cu:536),
  * `smith_waterman_kernel<<<1,32>>>` (cuda/LinearSmithWaterman.cu:263) and
@@ -110,6 +119,11 @@ int dpx_batch_fill(dpx_batch *b, void *stream);
 /* Run `repeats` fills back-to-back and return the mean device time of one fill in microseconds, measured with
  * hipEvents on the launch stream (the reference's kernel_time accumulator, V19.cu:531-586). */
 int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill);
+
+/* Device time of the most recent dpx_batch_fill() of a batch created with DPX_TIME_FILLS, without stalling the launch:
+ * the events are recorded on the fill's stream, this call waits only for the second one (the reference accumulates
+ * kernel_time the same way around its launches, V19.cu:531-586, but synchronously). */
+int dpx_batch_last_fill_usec(dpx_batch *b, double *usec);
 
 int dpx_batch_sync(dpx_batch *b); /* cudaDeviceSynchronize analogue for this batch's stream */
 
@@ -131,6 +145,24 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out);
  * Produces the three lines the reference prints (reference / relation / query; c++/backtrack.cpp:21-356).
  * Each buffer needs m+n+1 bytes; *len receives the alignment length. */
 int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine, char *qryLine, int32_t *len);
+
+/* The whole batch's result text, formatted on the device exactly as c++/main.cpp prints it: per pair
+ *     "<pair number> | <score>\n<reference line>\n<relation line>\n<query line>\n"
+ * (three empty lines for a zero-score local alignment, c++/LinearSmithWaterman.cpp:253-257), blocks in batch order, pair
+ * numbers counted from `firstPairNumber`.  Replaces the per-pair backtracking + string packing of the batched CUDA mains
+ * (cuda/LNW/LinearNeedlemanWunschV15.cu:168-172,372-425: packed variable-length result strings, one D2H of the real
+ * bytes; V19.cu:546-579 prints them).  _begin() is asynchronous (device traceback, block lengths, exclusive scan, packed
+ * copy, D2H of the offsets on the batch's stream); _end() waits, copies exactly the bytes of the text to pinned host memory
+ * and returns it: `*text` (`*bytes` long, also NUL-terminated) and `*offsets` (numPairs + 1 byte offsets of the blocks)
+ * stay valid until the batch is filled again or destroyed.  Two batches can be in flight: fill of batch k+1 overlaps
+ * traceback + D2H of batch k. */
+int dpx_batch_output_begin(dpx_batch *b, uint64_t firstPairNumber);
+int dpx_batch_output_end(dpx_batch *b, const char **text, size_t *bytes, const uint64_t **offsets);
+/* Like _end(), but the caller takes the (pinned) text buffer over and the batch can be destroyed at once -- its matrix pool
+ * is then free for the next batch while a printer thread is still writing the text (the reference prints batch k-1
+ * from host strings while batch k runs, V19.cu:546-579).  Give the buffer back with dpx_text_free(). */
+int dpx_batch_output_take(dpx_batch *b, char **text, size_t *bytes);
+int dpx_text_free(char *text);
 
 /* Sizes: numPairs, total cells (sum refLen*queryLen, the reference's numCells, c++/parseInput.cpp:100),
  * bytes of HBM the matrices occupy, algorithmic bytes of one fill. */

@@ -59,3 +59,23 @@ def test_empty_batch(gpu):
         b.fill()
         sc, _, _ = b.results()
         assert len(sc) == 0
+
+
+def test_explicit_device_argument(gpu):
+    """dpx_batch_create_on: a batch lives on the device it names; a device that does not exist is refused."""
+    sb = make_batch(3, 40, 50, seed=9)
+    n = gpu.device_count()
+    assert n >= 1
+    for bad in (n, n + 7, -2):
+        with pytest.raises(gpu.DpxError) as e:
+            gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, device=bad)
+        assert e.value.status == -1  # DPX_ERR_INVALID
+    import oracle_py as O
+    for dev in (-1, 0, n - 1):  # default device, first, last visible device
+        with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, device=dev) as b:
+            b.fill()
+            sc, er, ec = b.results()
+            for p in range(3):
+                o = O.lsw(sb.ref(p), sb.qry(p))
+                assert (sc[p], er[p], ec[p]) == (o.score, o.end_row, o.end_col)
+                assert np.array_equal(b.matrix(p).astype(np.int32), o.H)

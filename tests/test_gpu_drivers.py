@@ -62,6 +62,19 @@ def test_reference_main_cpp_drops_onto_the_engine(algo):
     assert "".join(blocks[p] for p in range(400)) == golden(algo)
 
 
+def test_reference_main_cpp_with_several_concurrent_leaders(monkeypatch):
+    """hostcpp/DpxPair.cpp deals the batches it forms from main.cpp's 20 threads to one leader per visible device;
+    DPX_CLASS_LEADERS=3 rehearses three concurrent leaders (all on this box's one GPU): same blocks."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "main_dropin_LNW")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_dropin_* not built (needs /root/reference at build time)")
+    monkeypatch.setenv("DPX_CLASS_LEADERS", "3")
+    _, blocks, _ = blocks_sorted(run([exe, "-pairs", os.path.join(G, "short400.txt")] + W["LNW"]))
+    assert "".join(blocks[p] for p in range(400)) == golden("LNW")
+    _, blocks, _ = blocks_sorted(run([os.path.join(HOST, "dpx_class_main"), "-pairs", os.path.join(G, "short400.txt")] + W["ANW"] + ["-algo", "ANW"]))
+    assert "".join(blocks[p] for p in range(400)) == golden("ANW")
+
+
 @pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
 def test_class_driver_and_batched_driver_match_reference_stdout(algo):
     subprocess.run(["make", "-s", "-C", HOST], check=True)
@@ -74,6 +87,9 @@ def test_class_driver_and_batched_driver_match_reference_stdout(algo):
     end = out.index("Elapsed time (usec): ")
     assert out[start:end] == golden(algo)
     assert re.search(r"^GCUPS: \d+\.\d+$", out, re.M) and "Num Pairs: 400" in out
+    # 11 batches: create / fill / traceback of batch k+1 are issued while batch k is in flight and batch k-1 is printing
+    out = run([os.path.join(HOST, "dpx_main"), "-pairs", pairs] + W[algo] + ["-algo", algo, "-batch", "37"])
+    assert out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time (usec): ")] == golden(algo)
 
 
 def test_tail_pairs_are_not_dropped(tmp_path):

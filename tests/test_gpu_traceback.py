@@ -98,3 +98,72 @@ def test_both_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
                     else:
                         o = O.lnw(refs, qry, *w[:3]); want = O.lnw_traceback(refs, qry, o)
                     assert b.traceback(p) == want, (algo, cached, r, quad, p, len(qry), len(refs))
+
+
+# ---- round 2: the device-formatted result text (packed variable-length blocks, one D2H of the real bytes) ----
+
+@pytest.mark.parametrize("algo,w", [("LSW", (3, -1, -2, -1)), ("LNW", (3, -1, -2, -1)), ("ANW", (3, -1, -3, -1))])
+def test_device_formatted_text_is_the_reference_stdout(gpu, algo, w):
+    """dpx_batch_output_begin / _end: the whole batch's blocks exactly as c++/main.cpp prints them, in one buffer."""
+    sb = parse_pairs_file(os.path.join(G, "short400.txt"))
+    want = gzip.open(os.path.join(G, f"short400_{algo}.out.gz"), "rb").read()
+    with gpu.Batch(CODE[algo], sb.sequences, sb.pairs, *w) as b:
+        b.fill()
+        b.output_begin(0)
+        text, offs = b.output_end()
+        assert text == want
+        assert offs[0] == 0 and offs[-1] == len(text) and all(text[o - 1:o] == b"\n" for o in offs[1:])
+        sc, _, _ = b.results()
+        for p in (0, 7, 399):   # the per-pair view reads the same buffer
+            assert _block(p, int(sc[p]), b.traceback(p), algo).encode("latin-1") == text[offs[p]:offs[p + 1]]
+        # other pair numbers (a later batch of a big file, a shard of rank r): only the headers change
+        first = 12345678901
+        b.output_begin(first)
+        text2, offs2 = b.output_end()
+        for p in (0, 9, 10, 99, 100, 399):
+            blk = text2[offs2[p]:offs2[p + 1]]
+            assert blk == f"{first + p}".encode() + text[offs[p]:offs[p + 1]][len(str(p)):]
+        assert len(text2) == len(text) + sum(len(str(first + p)) - len(str(p)) for p in range(400))
+        # refilling invalidates the text: it is rebuilt, identically
+        b.fill()
+        b.output_begin(0)
+        assert b.output_end()[0] == want
+
+
+def test_device_formatted_text_negative_and_zero_scores(gpu):
+    sb = from_strings([("0000000000", "1111"), ("0123", "0123"), ("", "01"), ("22", ""), ("3", "0")])
+    with gpu.Batch(CODE["LNW"], sb.sequences, sb.pairs, 3, -1, -2) as b:
+        b.fill()
+        b.output_begin(98)
+        text, offs = b.output_end()
+        sc, _, _ = b.results()
+        want = "".join(_block(98 + p, int(sc[p]), O.lnw_traceback(sb.ref(p), sb.qry(p), O.lnw(sb.ref(p), sb.qry(p), 3, -1, -2)), "LNW")
+                       for p in range(sb.num_pairs))
+        assert text.decode("latin-1") == want and sc[0] < 0 and "98 | -" in want and "\n100 | " in want
+    with gpu.Batch(CODE["LSW"], sb.sequences, sb.pairs, 3, -1, -2) as b:
+        b.fill()
+        b.output_begin(0)
+        text, _ = b.output_end()
+        assert text.startswith(b"0 | 0\n\n\n\n1 | 12\n0123\n****\n0123\n2 | 0\n\n\n\n")
+    with gpu.Batch(CODE["LSW"], sb.sequences, sb.pairs, 3, -1, -2, flags=gpu.SCORE_ONLY) as b:
+        b.fill()
+        with pytest.raises(gpu.DpxError) as e:
+            b.output_begin(0)
+        assert e.value.status == -7   # DPX_ERR_NO_MATRIX
+
+
+def test_two_batches_in_flight_text(gpu):
+    """What the pipelined driver does: begin() of batch k+1 is issued before end() of batch k."""
+    sb = parse_pairs_file(os.path.join(G, "short400.txt"))
+    want = gzip.open(os.path.join(G, "short400_LNW.out.gz"), "rb").read()
+    cuts = [0, 130, 131, 290, 400]
+    batches = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b = gpu.Batch(CODE["LNW"], sb.sequences, sb.pairs, 3, -1, -2, first_pair=lo, num_pairs=hi - lo, flags=gpu.TIME_FILLS)
+        b.fill()
+        b.output_begin(lo)
+        batches.append(b)
+    got = b"".join(b.output_end()[0] for b in batches)
+    for b in batches:
+        b.close()
+    assert got == want
