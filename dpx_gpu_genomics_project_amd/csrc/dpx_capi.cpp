@@ -74,7 +74,8 @@ public:
 
     /* a parked buffer of [need, 1.5 * need + 1 MiB], else a fresh allocation (after an out-of-memory: drop everything
      * that is parked anywhere and retry once) */
-    hipError_t take(void **out, size_t need, size_t *actual);
+    hipError_t take(void **out, size_t need, size_t *actual, bool *fresh = nullptr);
+    void discard(void *ptr) { raw_free(ptr); } /* a buffer that will not be parked */
     void park(void *ptr, size_t bytes);
     void drain();
 
@@ -93,7 +94,8 @@ private:
 
 void trim_all_caches();
 
-hipError_t BufCache::take(void **out, size_t need, size_t *actual) {
+hipError_t BufCache::take(void **out, size_t need, size_t *actual, bool *fresh) {
+    if (fresh) *fresh = false;
     {
         std::lock_guard<std::mutex> lk(mu_);
         size_t best = parked_.size();
@@ -114,6 +116,7 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual) {
      * it over: batches of one file differ by a few per cent, and pinning 8 MB costs ~1 ms every time it misses */
     const size_t want = need < ((size_t)1 << 30) ? align_up(need + need / 8, (size_t)64 << 10) : need;
     *actual = want;
+    if (fresh) *fresh = true;
     hipError_t e = raw_alloc(out, want);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -490,6 +493,45 @@ static uint64_t band_cells(long long m, long long n, long long B) {
     return (uint64_t)(s1 - s2 + M);
 }
 
+/* Where a big allocation lands in HBM matters: the same 22 GB matrix pool is written at 6.3 TB/s or at 6.05 TB/s by
+ * hipMemset depending on the allocation (measured, tools/pool_state.py: two modes, stable for the life of the allocation,
+ * and the fill kernels follow it one to one -- the "fast / slow box state" of round 1).  A fresh pool of a GiB or more
+ * is therefore probed: up to four candidate allocations are timed with a memset each, the fastest is kept and parked for
+ * every later batch, the others are freed.  Costs ~10 ms per candidate, once per process and pool size; DPX_POOL_PROBE=0
+ * turns it off. */
+static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace) {
+    if (const char *env = getenv("DPX_POOL_PROBE")) if (atoi(env) == 0) return first;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return first; }
+    auto probe = [&](void *p) -> float {
+        float best = 1e30f;
+        for (int k = 0; k < 2; k++) {
+            float ms = 1e30f;
+            if (hipEventRecord(e0, s) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
+                hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+            best = std::min(best, ms);
+        }
+        return best;
+    };
+    void *cand[4] = {first, nullptr, nullptr, nullptr};
+    float t[4] = {probe(first), 0, 0, 0};
+    int n = 1, bestIdx = 0;
+    for (; n < 4; n++) {
+        float lo = t[0], hi = t[0];
+        for (int k = 1; k < n; k++) { lo = std::min(lo, t[k]); hi = std::max(hi, t[k]); }
+        if (n >= 2 && hi > lo * 1.02f) break; /* both modes seen: the fast one is among the candidates */
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; } /* no room to shop around */
+        if (hipMalloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+        t[n] = probe(cand[n]);
+    }
+    for (int k = 1; k < n; k++) if (t[k] < t[bestIdx]) bestIdx = k;
+    if (trace.on) for (int k = 0; k < n; k++) fprintf(stderr, "[dpx] pool candidate %d at %p: memset %.3f ms%s\n", k, cand[k], t[k], k == bestIdx ? "  <- kept" : "");
+    for (int k = 0; k < n; k++) if (k != bestIdx && cand[k]) (void)hipFree(cand[k]);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return cand[bestIdx];
+}
+
 int dpx_batch_destroy(dpx_batch *b) {
     if (!b) return DPX_OK;
     PhaseTrace trace;
@@ -609,9 +651,10 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     /* LDS per wave: edge row(s) of int16 [n+2] + staged reference [n+128] */
     const size_t edgeBytes = align_up((size_t)(b->maxN + 2) * 2, 16);
     const size_t nEdges = params->algo == DPX_ALGO_ANW ? 2 : 1;
-    const size_t refBytes = align_up((size_t)b->maxN + 128, 16);
-    const size_t qBytes = align_up((size_t)b->maxM + 64 + 16, 16); /* banded kernel: staged query + 64 B of index slack */
-    const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 16, 16); /* staged query of the rolling multi-stripe schedule */
+    /* (+16 everywhere: a staged string starts up to 15 bytes into its buffer, at its own address mod 16 -- stage_bytes) */
+    const size_t refBytes = align_up((size_t)b->maxN + 128 + 16, 16);
+    const size_t qBytes = align_up((size_t)b->maxM + 64 + 32, 16); /* banded kernel: staged query + 64 B of index slack */
+    const size_t rollQ = align_up((size_t)b->maxM + 64 * 16 + 32, 16); /* staged query of the rolling multi-stripe schedule */
     const size_t perWave = banded ? qBytes + refBytes : edgeBytes * nEdges + refBytes + rollQ;
     b->ldsBytes = perWave * (DPX_FILL_THREADS / 64);
     /* Store-bound fills run ~2 % faster with 3-4 waves per SIMD than with 6-7 (fewer write streams in flight,
@@ -870,8 +913,11 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     }
     if (b->store && b->matElems) {
         void *pool = nullptr;
-        CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes));
+        bool fresh = false;
+        CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes, &fresh));
+        if (fresh && b->matPoolBytes >= ((size_t)1 << 30)) pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace);
         b->dMat = (int16_t *)pool;
+
     }
     trace.mark("create: H2D pairs+matrix pool");
 #undef CREATE_TRY

@@ -68,6 +68,13 @@ __device__ __forceinline__ unsigned char *stage_bytes(unsigned char *dst16, cons
     return dst16 + a;
 }
 
+/* four bytes from an arbitrary address: two aligned dword loads + v_alignbyte_b32 */
+__device__ __forceinline__ uint32_t load4(const unsigned char *p) {
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(p - sh);
+    return __builtin_amdgcn_alignbyte(al[1], al[0], sh);
+}
+
 /* the R query characters of a lane's rows (row0 .. row0+R-1 of `qry`) from R/4 + 1 aligned dword loads and
  * v_alignbyte_b32 instead of R byte loads; rows past the query's end get 0x100 (matches no byte) */
 template <int R>
@@ -278,8 +285,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
     int16_t *edge = reinterpret_cast<int16_t *>(my); /* edge[j], j = 0..n+1: H of the row above the current stripe */
-    unsigned char *refl = my + a.ldsRefOff;           /* refl[64 + (j-1)], 64 bytes of slack either side */
-    for (int x = lane; x < n; x += 64) refl[64 + x] = ref[x];
+    /* refl[64 + (j-1)], 64 bytes of slack either side; staged with 16-byte loads (stage_bytes) */
+    const unsigned char *refl = stage_bytes(my + a.ldsRefOff + 64, ref, n, lane, 64) - 64;
     /* row-0 border (LinearNeedlemanWunsch.cpp:38-41; all zero for SW) is the first stripe's "row above" */
     for (int x = lane; x <= n + 1; x += 64) edge[x] = (int16_t)(LOCAL ? 0 : x * gap);
 
@@ -294,15 +301,14 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
         /* ---------- rolling schedule: a lane that finishes column n of its stripe starts column 1 of the next one
          * on the following step, so the skew ramp is paid once per pair instead of once per stripe and every
          * chunk between the two ramps is a whole one. ---------- */
-        unsigned char *ql = my + a.ldsQryOff; /* staged query: the stripe switch must not wait on global memory */
-        for (int x = lane; x < m; x += 64) ql[x] = qry[x];
+        const unsigned char *ql = stage_bytes(my + a.ldsQryOff, qry, m, lane, 64); /* staged query: the stripe switch must not wait on global memory */
         int row0 = lane * R;
         int nrows = min(max(m - row0, 0), R);
         int jl = 1 - lane; /* this lane's column; <= 0: not started yet */
         int kl = 0;        /* this lane's stripe */
+        load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
             st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
             st.key[r] = 0u;
         }
@@ -364,9 +370,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             const int nrows = min(max(m - row0, 0), R);
             const bool laneHasRows = nrows > 0;
             const bool hasNext = (k + 1 < S);
+            load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
                 st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
                 st.key[r] = 0u;
             }
@@ -691,7 +697,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
         const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pq.refIdx);
         const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pq.qryIdx);
         unsigned char *rl = refl0 + (size_t)(ord & 1) * a.ldsBufStride, *ql = ql0 + (size_t)(ord & 1) * a.ldsBufStride;
-        for (int x = lane; x < n; x += 64) rl[64 + x] = ref[x];
+        for (int x = lane; x < n; x += 64) rl[64 + x] = ref[x]; /* (opt-in schedule: byte staging kept, both buffers share fixed offsets) */
         for (int x = lane; x < m; x += 64) ql[x] = qry[x];
     };
     stage(0);
@@ -936,7 +942,13 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
     uint32_t *edge = reinterpret_cast<uint32_t *>(my);                    /* packed edge[j], j = 0..n+1 */
     uint16_t *refl = reinterpret_cast<uint16_t *>(my + a.ldsRefOff);      /* refl[64 + (j-1)] = A char << 8 | B char */
-    for (int x = lane; x < n; x += 64) refl[64 + x] = (uint16_t)((refA[x] << 8) | refB[x]);
+    for (int x = 4 * lane; x < n; x += 256) { /* four columns per lane and trip: 2 + 2 aligned dword loads, one 8-byte LDS store */
+        const uint32_t a4 = load4(refA + x), b4 = load4(refB + x);
+        uint2 w;
+        w.x = __builtin_amdgcn_perm(a4, b4, 0x05010400u); /* {B0, A0, B1, A1}: entry j = A char << 8 | B char */
+        w.y = __builtin_amdgcn_perm(a4, b4, 0x07030602u);
+        *reinterpret_cast<uint2 *>(refl + 64 + x) = w;    /* refl + 64 is 8-byte aligned (ldsRefOff is a multiple of 16) */
+    }
     for (int x = lane; x <= n + 1; x += 64) {
         const uint16_t b = (uint16_t)(LOCAL ? 0 : x * gap);
         edge[x] = ((uint32_t)b << 16) | b;
@@ -953,9 +965,12 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         const int nrows = min(max(m - row0, 0), R);
         const bool laneHasRows = nrows > 0;
         const bool hasNext = (k + 1 < S);
+        int qa[R], qb[R];
+        load_query_rows<R>(qa, qryA, row0, nrows);
+        load_query_rows<R>(qb, qryB, row0, nrows);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            st.qc[r] = (r < nrows) ? (((uint32_t)qryA[row0 + r] << 16) | qryB[row0 + r]) : 0x01000100u;
+            st.qc[r] = ((uint32_t)qa[r] << 16) | (uint32_t)qb[r]; /* rows past the end: 0x0100 in both halves */
             const uint16_t b = (uint16_t)(LOCAL ? 0 : (row0 + 1 + r) * gap);
             st.Hl[r] = ((uint32_t)b << 16) | b;
             st.rmax[r] = 0u;
@@ -1125,8 +1140,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
     int16_t *edgeH = reinterpret_cast<int16_t *>(my);
     int16_t *edgeD = reinterpret_cast<int16_t *>(my + a.ldsEdge2Off);
-    unsigned char *refl = my + a.ldsRefOff;
-    for (int x = lane; x < n; x += 64) refl[64 + x] = ref[x];
+    const unsigned char *refl = stage_bytes(my + a.ldsRefOff + 64, ref, n, lane, 64) - 64;
     /* row-0 border H[0][j] = o + j*e (AffineNeedlemanWunsch.cpp:50-53); D[0][j] is the virtual DPX_NEG (k == 0 below) */
     for (int x = lane; x <= n + 1; x += 64) { edgeH[x] = (int16_t)(o + x * e); edgeD[x] = 0; }
 
@@ -1137,14 +1151,13 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
 
     if (STORE && S >= 2 && n >= 128) {
         /* ---------- rolling schedule (see k_linear_fill): lanes run straight on into the next stripe ---------- */
-        unsigned char *ql = my + a.ldsQryOff;
-        for (int x = lane; x < m; x += 64) ql[x] = qry[x];
+        const unsigned char *ql = stage_bytes(my + a.ldsQryOff, qry, m, lane, 64);
         int row0 = lane * R;
         int nrows = min(max(m - row0, 0), R);
         int jl = 1 - lane, kl = 0;
+        load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
             st.Hl[r] = o + (row0 + 1 + r) * e;
             st.Il[r] = DPX_NEG;
             st.Dl[r] = DPX_NEG;
@@ -1209,9 +1222,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
             const int nrows = min(max(m - row0, 0), R);
             const bool laneHasRows = nrows > 0;
             const bool hasNext = (k + 1 < S);
+            load_query_rows<R>(st.qc, qry, row0, nrows);
     #pragma unroll
             for (int r = 0; r < R; r++) {
-                st.qc[r] = (r < nrows) ? (int)qry[row0 + r] : 0x100;
                 st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (:43-46) */
                 st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
                 st.Dl[r] = DPX_NEG;
@@ -1457,10 +1470,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
-    unsigned char *qL = my;
-    unsigned char *rL = my + a.ldsRefOff;
-    for (int x = lane; x < m; x += 64) qL[x] = qry[x];
-    for (int x = lane; x < n; x += 64) rL[x] = ref[x];
+    const unsigned char *qL = stage_bytes(my, qry, m, lane, 64);            /* 16-byte loads; each buffer has 16 spare bytes for the shift */
+    const unsigned char *rL = stage_bytes(my + a.ldsRefOff, ref, n, lane, 64);
 
     BandState<C> st;
     { /* character windows of the virtual anti-diagonal a = 1 (the first real step then slides one of them) */
