@@ -48,6 +48,15 @@ WORKLOADS = {
 BAND = 128
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the sources every device kernel is built from (changes exactly when a kernel may have changed)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("dpx_kernels.hip", "dpx_kernels.h", "dpx_layout.h", "dpx_prims.hpp"):
+        h.update(open(os.path.join(ROOT, "dpx_gpu_genomics_project_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 class _DevArray:
     """Zero-copy view of engine-owned device memory for torch (RCCL gather source)."""
 
@@ -78,6 +87,29 @@ def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pa
             out = {"value": round(o2["fill_gcups"], 4), "unit": "GCUPS", "cores": min(20, cores), "host_cores": cores, "kind": "reference",
                    "sample": desc + "; reference classes built -O2, 20 pthreads x 20 pairs per batch (c++/main.cpp:18-19)",
                    "threads": 20, "align_gcups_O2": round(o2["align_gcups"], 4)}
+            # every host core: as many concurrent 20-thread reference processes as fit the host (SURVEY 8d "all host cores"), each
+            # timing its own 400-pair slice (one full 20 x 20 batch of the reference driver) of the same batch at the same time
+            procs = max(1, min(cores // 20, sb.num_pairs // 400, 16))
+            if procs > 1:
+                files = []
+                for k in range(procs):
+                    lo, hi = 400 * k, 400 * (k + 1)
+                    base = int(sb.pairs["queryIdx"][lo - 1] + sb.pairs["querySize"][lo - 1] + 1) if lo else 0  # start of pair lo's record
+                    end_k = int(sb.pairs["queryIdx"][hi - 1] + sb.pairs["querySize"][hi - 1] + 1)
+                    prs = sb.pairs[lo:hi].copy()
+                    prs["referenceIdx"] -= base
+                    prs["queryIdx"] -= base
+                    fk = os.path.join(td, f"slice{k}.txt")
+                    write_pairs_file(SynthBatch(sb.sequences[base:end_k], prs, sb.m, sb.n), fk)
+                    files.append(fk)
+                t0 = time.perf_counter()
+                ps = [subprocess.Popen([ref_o2, "time", algo_name, fk] + args[2:] + ["400"], stdout=subprocess.PIPE, text=True) for fk in files]
+                outs = [json.loads(p_.communicate()[0]) for p_ in ps]
+                wall = time.perf_counter() - t0
+                # the processes run side by side: throughput = all their cells / the slowest one's fill time
+                out["value_all_cores"] = round(sum(o["cells"] for o in outs) / max(o["fill_sec"] for o in outs) / 1e9, 4)
+                out["all_cores"] = {"processes": procs, "threads": 20 * procs, "host_cores": cores, "pairs": 400 * procs,
+                                    "wall_sec_incl_align": round(wall, 2)}
             if os.path.exists(ref_o0):  # the reference's own flags (c++/Makefile:2), on a tenth of the sample
                 n0 = max(npairs // 10, 1)
                 o0 = json.loads(subprocess.run([ref_o0, "time"] + args + [str(n0)], capture_output=True, text=True, check=True).stdout)
@@ -244,11 +276,15 @@ def main():
         total_cells = info["cells"] * world
         value = total_cells * args.steps / elapsed / 1e9
         achieved = info["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per fill from the PMC passes of tools/profile_all.sh (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate runs),
+        # recorded together with a hash of the kernel sources: a figure measured on other kernels is reported as stale
+        traffic, traffic_stale = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(args.workload)
+                rec = json.load(open(prof))
+                traffic = rec.get("workloads", {}).get(args.workload)
+                traffic_stale = rec.get("kernel_source_sha256") != kernel_source_hash()
             except Exception:
                 traffic = None
         out = {
@@ -263,7 +299,7 @@ def main():
                        "precondition_fills": precondition_fills, "kernel": desc["kernel"],
                        "rows_per_lane": desc["rows_per_lane"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                          "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1)},
         }

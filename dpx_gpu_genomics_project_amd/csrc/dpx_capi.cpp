@@ -255,6 +255,9 @@ struct dpx_batch {
     bool streamed = false; /* uniform batch on the stream schedule (k_linear_stream) */
     size_t streamLds = 0;
     bool packed = false;
+    bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
+    int splitWaves = 0;
+    size_t splitLds = 0;
     bool quad = false;     /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
                               descriptors in dCouples, launch arguments in pkArgs */
     int32_t *dCouples = nullptr;
@@ -753,6 +756,29 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         }
         b->packed = !couples.empty();
     }
+    /* Split path (small batches: fewer pairs than the chip has wave slots worth filling): one workgroup per pair, one wave per
+     * stripe of 64 * R rows with R = 4 (2 for queries up to 256 rows), stripes concurrent (k_linear_split).  1000 pairs of
+     * 512 x 512 become 2000 waves with half the dependent chain per step.  DPX_SPLIT=0/1 overrides. */
+    {
+        bool anyEmpty = false;
+        for (size_t i = 0; i < numPairs && !anyEmpty; i++) anyEmpty = b->pairs[i].m <= 0 || b->pairs[i].n <= 0;
+        const int sR = b->maxM > 4096 ? 8 : b->maxM > 256 ? 4 : 2;
+        const int sW = dpx_tiled_stripes(b->maxM, sR);
+        const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
+        const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;
+        const bool shape = linearAlgo && b->store && !b->quad && !b->packed && !anyEmpty && numPairs > 0 && sW >= 2 && sW <= 16 && lds <= 160u * 1024u;
+        /* measured (tools/ab_fill.py, DPX_SPLIT=0/1): 100 x 512^2 +25 %, 500 x 1024^2 +39 %, 1000 x 512^2 +1 %, 1000 x 1024^2 (4000 waves)
+         * -13 %: worth it while the split batch stays within about two waves per SIMD */
+        bool useSplit = shape && numPairs * (size_t)sW <= 2304;
+        if (const char *env = getenv("DPX_SPLIT")) useSplit = atoi(env) != 0 && shape;
+        if (useSplit) {
+            b->split = true;
+            b->R = sR;
+            b->splitWaves = sW;
+            b->splitLds = lds;
+            for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 32; b->pairs[i].rows = (uint16_t)sR; }
+        }
+    }
     trace.mark("create: validate+geometry+launch lists");
     CREATE_TRY(stream_take(&b->stream));
     trace.mark("create: stream");
@@ -816,7 +842,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
     int numStreams = 0;
     {
-        bool want = b->store && !b->packed && !b->quad && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
+        bool want = b->store && !b->packed && !b->quad && !b->split && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
                     b->pairs[0].m > 0 && b->pairs[0].n >= 128;
         /* opt-in: bit-exact and 3 % fewer bytes written, but not faster than one launch-scheduled wave per pair -- the
          * fill is bound by store instructions per CU-cycle either way (profiles/README.md) */
@@ -846,8 +872,9 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     if (b->store) {
         int group = 64;
         if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 4096) group = v; }
-        const uint32_t chunkElems = banded ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
+        const uint32_t chunkElems = (banded || b->split) ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
         auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
+            if (pd.lanes == 32) return dpx_split_chunks(pd.m, pd.n, b->R);
             return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
         };
         uint64_t off = 0;
@@ -939,6 +966,11 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     a.uniM = numPairs ? b->pairs[0].m : 0;
     a.uniN = numPairs ? b->pairs[0].n : 0;
     a.ldsBufStride = 0;
+    if (b->split) { /* [control 512 B][staged reference][edge rows, one per stripe boundary] */
+        a.ldsRefOff = 512u;
+        a.ldsQryOff = (uint32_t)(512 + align_up((size_t)b->maxN + 128 + 16, 16));
+        a.ldsBufStride = (uint32_t)align_up((size_t)b->maxN + 2, 8);
+    }
     if (b->streamed) { /* per wave: edge row + 2 x (reference [n+128] + query [m + 64R + 16]) */
         const size_t refB = align_up((size_t)b->maxN + 128, 16), qB = align_up((size_t)b->maxM + 64 * 16 + 16, 16);
         a.ldsRefOff = (uint32_t)edgeBytes;
@@ -1013,6 +1045,8 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     } else if (b->packed) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
         if (e == hipSuccess) e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+    } else if (b->split) {
+        e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, s);
     } else if (b->streamed) {
         e = dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
     } else {
@@ -1288,7 +1322,7 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? "k_banded_fill" : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_lanes" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d",
              names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,

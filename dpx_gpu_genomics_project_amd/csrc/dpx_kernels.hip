@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dpx_kernels.h"
 #include "dpx_layout.h"
 #include "dpx_prims.hpp"
@@ -824,6 +826,153 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
             const int pd = pair_at(cnt - 1);
             a.score[pd] = v; a.endRow[pd] = m; a.endCol[pd] = n;
+        }
+    }
+}
+
+/* =====================================================================================================
+ * Split kernel for SMALL batches (BASELINE configs[1]: 1000 pairs of 512 x 512 -- one wave per pair leaves the chip with
+ * one wave per SIMD, and a lone wave issues a vector instruction only every 4 cycles).  One workgroup per pair, one WAVE
+ * PER STRIPE: wave w fills rows [w*64R, (w+1)*64R) with R = 4 (or 2), all stripes at the same time, wave w+1 running
+ * ~90 columns behind wave w and taking its "row above" from the LDS edge row wave w's lane 63 writes -- the stripe
+ * hand-off of cuda/LNW/LinearNeedlemanWunschV12.cu:110-113,141-143 (warpEdgeScore), made concurrent.  Progress is
+ * published through LDS every 8 columns (release) and checked every 16 (acquire).  1000 pairs become 2000-4000 waves
+ * with half (a quarter) of the dependent chain per step.  Stores stay 16 bytes per lane: G = 8/R steps are collected in
+ * registers (dpx_layout.h, split layout); every stripe owns its chunks, so ramp chunks are written whole.
+ * ===================================================================================================== */
+#define DPX_SPLIT_MAX_WAVES 16
+template <int R, bool LOCAL>
+__global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int G = 8 / R; /* steps per 16-byte store */
+    static_assert(R == 2 || R == 4 || R == 8, "rows per lane");
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int p = blockIdx.x;
+    if (a.order) p = a.order[p];
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m; /* host guarantees m > 0, n > 0 */
+    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    const int W = dpx_tiled_stripes(m, R);
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    /* LDS: [control: progress[16], done, pad | per-wave results 16 x 16 B][staged reference][edge rows, one per stripe boundary] */
+    int *ctrl = reinterpret_cast<int *>(smem);
+    int *result = ctrl + 32;
+    if (threadIdx.x < 32) ctrl[threadIdx.x] = 0;
+    const unsigned char *refl = stage_bytes(smem + a.ldsRefOff + 64, ref, n, (int)threadIdx.x, (int)blockDim.x) - 64; /* refl[64 + (j-1)] */
+    __syncthreads(); /* every wave of the workgroup is still here; surplus waves leave afterwards */
+    if (w >= W) return;
+    int16_t *edgeMine = reinterpret_cast<int16_t *>(smem + a.ldsQryOff) + (size_t)w * a.ldsBufStride;       /* bottom row of this stripe */
+    const int16_t *edgePrev = edgeMine - a.ldsBufStride;                                                        /* ... of the stripe above */
+
+    const int row0 = w * 64 * R + lane * R;
+    const int nrows = min(max(m - row0, 0), R);
+    LinState<R, LOCAL> st;
+    load_query_rows<R>(st.qc, qry, row0, nrows);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+        st.key[r] = 0u;
+    }
+    st.dtop = LOCAL ? 0 : row0 * gap;
+    const bool hasNext = w + 1 < W;
+    const int rowsHere = min(m - w * 64 * R, 64 * R);
+    const int storeLanes = min(64, (((rowsHere + R - 1) / R) + 7) & ~7); /* row-owning lanes, rounded up to whole 128-byte lines */
+    const uint32_t SS = dpx_split_stripe_steps(n, R); /* n + 63 rounded up to whole 16-step blocks */
+    const size_t cs = pr.chunkStride;
+    int16_t *tile = a.mat + pr.matOff + ((size_t)w * (SS / G)) * cs + (size_t)lane * 8;
+    const unsigned char *rp = refl + 64 - lane; /* rp[t] = reference character of column j = t - lane + 1 */
+    auto wait_for = [&](const int need) {       /* wave-uniform: the stripe above has published `need` columns of its bottom row */
+        while (__hip_atomic_load(&ctrl[w - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    };
+    /* lane 63 writes the stripe's bottom row; the other lanes write the same instruction's worth into a 32-byte dump, so the
+     * edge write costs one ds_write_b16 per step and no exec juggling */
+    int16_t *dump = reinterpret_cast<int16_t *>(smem + 384) + 16 * 0;
+    uint32_t acc[4];
+    /* one block of 16 steps; MASKED: the skew ramps, where a lane may be before column 1 or past column n */
+    auto block16 = [&](const int tb, auto maskedTag) {
+        constexpr bool MASKED = decltype(maskedTag)::value;
+        if (w > 0) wait_for(min(tb + 17, n));
+        int16_t *ew = (hasNext && lane == 63) ? edgeMine + (tb - 62) : dump; /* ew[g] = edgeMine[j] of step tb + g */
+        const unsigned char *rpb = rp + tb;
+        const int16_t *epb = edgePrev + tb;
+        int rcN = rpb[0];
+        int e0N = (w == 0) ? (LOCAL ? 0 : (tb + 1) * gap) : (int)epb[1];
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int t = tb + g;
+            const int rc = rcN, e0 = e0N;
+            rcN = rpb[g + 1];
+            e0N = (w == 0) ? (LOCAL ? 0 : (t + 2) * gap) : (int)epb[g + 2]; /* (entries past n are never used) */
+            const int upin = wave_shr1(st.Hl[R - 1], e0);
+            const int j = t - lane + 1;
+            if constexpr (MASKED) {
+                if (j >= 1 && j <= n) {
+                    lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
+                    if (hasNext && lane == 63) edgeMine[j] = (int16_t)st.Hl[R - 1];
+                }
+            } else {
+                lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
+                ew[g] = (int16_t)st.Hl[R - 1];
+            }
+            if constexpr (R == 8) {
+                acc[0] = pack_lo16(st.Hl[0], st.Hl[1]); acc[1] = pack_lo16(st.Hl[2], st.Hl[3]);
+                acc[2] = pack_lo16(st.Hl[4], st.Hl[5]); acc[3] = pack_lo16(st.Hl[6], st.Hl[7]);
+            } else if constexpr (R == 4) {
+                acc[2 * (g % G)] = pack_lo16(st.Hl[0], st.Hl[1]); acc[2 * (g % G) + 1] = pack_lo16(st.Hl[2], st.Hl[3]);
+            } else {
+                acc[g % G] = pack_lo16(st.Hl[0], st.Hl[1]);
+            }
+            if ((g % G) == G - 1 && t - (G - 1) < n + 63) { /* whole chunks, also on the skew ramps (see lin_step); nothing past the last step */
+                if (lane < storeLanes) {
+                    u32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+                    stream_store(reinterpret_cast<u32x4 *>(tile + (size_t)(t / G) * cs), v);
+                }
+            }
+            /* publish the bottom row's progress every 8 columns (lane 63 ran column t - 62 in this step) */
+            if ((g & 7) == 7 && hasNext && t >= 63) {
+                if (lane == 63) __hip_atomic_store(&ctrl[w], min(t - 62, n), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    {
+        int tb = 0;
+        const int steps = (int)SS;
+        for (; tb < steps && tb < 64; tb += 16) block16(tb, std::true_type{});
+        for (; tb + 16 <= n; tb += 16) block16(tb, std::false_type{}); /* every lane inside [1, n] for all 16 steps */
+        for (; tb < steps; tb += 16) block16(tb, std::true_type{});
+    }
+    if (hasNext && lane == 63) __hip_atomic_store(&ctrl[w], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    /* results: every wave leaves its candidate in LDS; the wave that arrives last combines them */
+    int bestv = 0, bestrow = 0, bestcol = 0;
+    if constexpr (LOCAL) {
+        lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
+        const unsigned long long mine = ((unsigned long long)(unsigned)bestv << 32) | (unsigned)(0x7FFFFFFF - bestrow);
+        const unsigned long long top = wave_max_u64(mine);
+        if (mine == top && (bestv > 0 ? true : lane == 0)) { result[4 * w] = bestv; result[4 * w + 1] = bestrow; result[4 * w + 2] = bestcol; }
+    } else {
+        const int lm = (m - 1 - w * 64 * R) / R, rm = (m - 1) % R; /* owner of row m (in the last stripe) */
+        if (w == W - 1 && lane == lm) {
+            int v = st.Hl[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
+            a.score[p] = v; a.endRow[p] = m; a.endCol[p] = n;
+        }
+    }
+    if constexpr (LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&ctrl[16], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == W - 1 && lane == 0) { /* first strict maximum in row-major order: max score, then the first stripe holding it */
+            int bv = 0, br = 0, bc = 0;
+            for (int k = 0; k < W; k++) {
+                const int v = __hip_atomic_load(&result[4 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v > bv) { bv = v; br = result[4 * k + 1]; bc = result[4 * k + 2]; }
+            }
+            a.score[p] = bv; a.endRow[p] = bv > 0 ? br : 0; a.endCol[p] = bv > 0 ? bc : 0;
         }
     }
 }
@@ -1729,7 +1878,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
      * batches with enough lanes in flight that the walk is bound by sector requests (measured: 100k short pairs -25 %);
      * smaller batches are bound by the latency of one dependent load per step instead, and there the plain
      * three-loads-in-parallel step is the shorter chain (5000 x 1024^2: cached +40 %, 20k x 300^2: +10 %).  The host decides. */
-    const bool cached = (algo == DPX_K_LSW || algo == DPX_K_LNW) && v.R >= 8 && cachedWalk;
+    const bool cached = (algo == DPX_K_LSW || algo == DPX_K_LNW) && v.R >= 8 && cachedWalk && pr.lanes != 32;
     if (cached) {
         const int g = a.gapOpen;
         TileWalker w{a.mat, pr.matOff, pr.chunkStride, pr.lanes, n, dpx_log2(v.R), algo == DPX_K_LNW ? g : 0};
@@ -2108,6 +2257,24 @@ hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool s
     default: return hipErrorInvalidValue;
     }
 #undef DPX_LANES_CASE
+}
+
+/* split kernel (small batches): one workgroup of `waves` waves per pair, a.numPairs workgroups */
+hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    if (waves < 1 || waves > DPX_SPLIT_MAX_WAVES) return hipErrorInvalidValue;
+    const bool local = algo == DPX_K_LSW;
+    dim3 grid((unsigned)a.numPairs);
+#define DPX_SPLIT_CASE(R_)                                                                                                   \
+    case R_: return local ? launch_lanes_kernel(k_linear_split<R_, true>, a, grid, 64 * waves, ldsBytes, stream)             \
+                          : launch_lanes_kernel(k_linear_split<R_, false>, a, grid, 64 * waves, ldsBytes, stream);
+    switch (R) {
+        DPX_SPLIT_CASE(2)
+        DPX_SPLIT_CASE(4)
+        DPX_SPLIT_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef DPX_SPLIT_CASE
 }
 
 /* stream schedule (uniform batches): a.numStreams persistent waves, each fills its pairs back to back */

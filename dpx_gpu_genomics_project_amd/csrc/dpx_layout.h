@@ -47,7 +47,8 @@ typedef struct dpx_pair_dev {
     int32_t qryIdx, m;  /* query offset / length      (rows)    */
     uint64_t matOff;    /* first int16 element of this pair's chunk 0 */
     uint32_t chunkStride; /* int16 elements between consecutive chunks (steps) of this pair */
-    uint16_t lanes;       /* 64: wavefront-tiled layout (one wave per pair); 16: 8x8-tile layout (quad kernels, 4 pairs per wave) */
+    uint16_t lanes;       /* layout tag -- 64: wavefront-tiled (one wave per pair); 16: 8x8 tiles (lane-packed kernels, several pairs per
+                             wave); 32: split (k_linear_split, one wave per stripe) */
     uint16_t rows;        /* rows per lane of the kernel that fills this pair (quad batches mix 8 and 16); 0 = the batch's */
 } dpx_pair_dev;
 
@@ -107,8 +108,27 @@ DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t 
     uint64_t T = (uint64_t)k * (uint64_t)n + (uint64_t)(j - 1) + (uint64_t)l;
     return T * (uint64_t)chunkStride + (uint64_t)dpx_tile_off(R, plane, l, r);
 }
+/* Split layout (pairs filled by k_linear_split, dpx_pair_dev.lanes == 32): the stripes of a pair are filled by different
+ * waves of one workgroup at the same time, so every stripe owns its chunks -- stripe k runs its n + 63 steps in
+ * T = k*SS + (j-1) + l with the stripe stride SS = n + 63 rounded up to a multiple of 16 -- and G = 8/R steps of a lane
+ * (R = 2, 4 or 8 rows of 2 bytes) share one 16-byte store:
+ *       element(i, j) = matOff + (T / G) * chunkStride + l*8 + (T % G)*R + r          (one plane; 1-KiB chunks) */
+DPX_HD int dpx_split_group(int R) { return R >= 8 ? 1 : 8 / R; }
+DPX_HD uint32_t dpx_split_stripe_steps(int n, int R) { (void)R; return ((uint32_t)n + 63u + 15u) & ~15u; } /* whole 16-step blocks of the kernel */
+DPX_HD uint64_t dpx_split_chunks(int m, int n, int R) {
+    if (m <= 0 || n <= 0) return 0;
+    return (uint64_t)dpx_tiled_stripes(m, R) * (uint64_t)(dpx_split_stripe_steps(n, R) / (uint32_t)dpx_split_group(R));
+}
+DPX_HD uint64_t dpx_split_index(int i, int j, int n, int R, uint32_t chunkStride) {
+    const int sr = dpx_log2(R), sg = 3 - sr, i0 = i - 1; /* G = 2^sg */
+    const int k = i0 >> (sr + 6), l = (i0 >> sr) & 63, r = i0 & (R - 1);
+    const uint64_t T = (uint64_t)k * (uint64_t)dpx_split_stripe_steps(n, R) + (uint64_t)(j - 1) + (uint64_t)l;
+    return (T >> sg) * (uint64_t)chunkStride + (uint64_t)((l << 3) + (((int)T & ((1 << sg) - 1)) << sr) + r);
+}
+
 /* either layout, by the pair's `lanes` tag */
 DPX_HD uint64_t dpx_cell_index(int i, int j, int n, int R, int plane, int planes, uint32_t chunkStride, uint32_t lanes) {
+    if (lanes == 32) return dpx_split_index(i, j, n, R, chunkStride);
     return lanes == 16 ? dpx_tile8_index(i, j, plane, planes, chunkStride) : dpx_tiled_index(i, j, n, R, plane, chunkStride);
 }
 
