@@ -35,6 +35,7 @@ typedef struct dpx_fill_args {
     /* stream schedule (uniform batches): wave s of numStreams fills pairs s, s+numStreams, ... back to back */
     int32_t numStreams, uniM, uniN;
     uint32_t ldsBufStride;      /* bytes between the two staged (reference, query) buffers */
+    int32_t rampLines;          /* 1: skew-ramp steps store only the 128-byte lines that hold cells (byte-bound batches); 0: whole chunks */
 } dpx_fill_args;
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream);

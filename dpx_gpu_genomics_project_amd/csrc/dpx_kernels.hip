@@ -166,6 +166,26 @@ __device__ __forceinline__ int store_lanes(const int m) {
     return min(64, (owning + perLine - 1) / perLine * perLine);
 }
 
+/* Skew ramps: in step t of a stripe of n columns only the lanes t-n+1 .. t are on a real cell.  Storing the whole chunk writes
+ * 6 % of padding at 1024 x 1024 (12 % at 512 x 512); storing exactly the lanes on a cell leaves partly written 128-byte lines,
+ * which cost more than they save (profiles/README.md).  So the ramp steps store the lanes on a cell ROUNDED OUT TO WHOLE LINES
+ * (8 lanes x 16 B; 16 / 32 lanes for 4 / 2 rows per lane): nearly all of the padding stays unwritten, every written line is
+ * whole.  DPX_EXP_FULLRAMP=1 builds the round-1 behaviour (whole chunks) for A/B runs. */
+#ifndef DPX_EXP_FULLRAMP
+#define DPX_EXP_FULLRAMP 0
+#endif
+template <int R>
+__device__ __forceinline__ bool ramp_stores(const int lane, const int t, const int n, const int rampLines) {
+#if DPX_EXP_FULLRAMP
+    return true;
+#else
+    if (!rampLines) return true; /* small batches are bound by the latency of a step, not by bytes: whole chunks are cheaper there */
+    constexpr int perLine = 128 / (2 * (R < 8 ? R : 8));
+    const int lo = max(t - n + 1, 0) & ~(perLine - 1), hi = (min(t, 63) + perLine) & ~(perLine - 1);
+    return lane >= lo && lane < hi;
+#endif
+}
+
 /* the R chained cells of one lane for one column (shared by the striped and the rolling schedule) */
 template <int R, bool LOCAL, bool KEYS>
 __device__ __forceinline__ void lin_cells(LinState<R, LOCAL> &st, const int upin, const int rc, const int j, const int match,
@@ -237,7 +257,7 @@ template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
                                          const bool laneHasRows, const int match, const int mismatch, const int gap,
                                          const int e0, const int rc, int16_t *edge, const bool writeEdge,
-                                         int16_t *tileDst, const int storeLanes) {
+                                         int16_t *tileDst, const int storeLanes, const int rampLines) {
     const int j = t - lane + 1;
     /* cross-lane traffic happens with all lanes enabled: a finished lane must still feed its neighbour */
     const int upin = wave_shr1(st.Hl[R - 1], e0);
@@ -259,7 +279,9 @@ __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, co
      * with a partly written 64-B sector becomes a read-modify-write at the HBM.  The extra bytes land in the skew
      * padding of the pair's block, which nothing ever reads. */
     if constexpr (STORE && (!MASKED || WHOLE) && !(MASKED && DPX_EXP_NORAMPSTORE)) {
-        if (lane < storeLanes) store_words<R>(tileDst, w); /* storeLanes == 64 unless the pair is shorter than the stripe */
+        bool doStore = lane < storeLanes; /* storeLanes == 64 unless the pair is shorter than the stripe */
+        if constexpr (MASKED) doStore = doStore && ramp_stores<R>(lane, t, n, rampLines);
+        if (doStore) store_words<R>(tileDst, w);
     }
 }
 
@@ -351,7 +373,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             } else if constexpr (STORE) {
                 lin_pack<R, LOCAL>(st, w);
             }
-            if constexpr (STORE) store_words<R>(tile + (size_t)T * cs, w); /* whole chunk, every step */
+            if constexpr (STORE) { /* whole chunk every step; on the pair's two ramps only the lines with cells (ramp_stores) */
+                if (ramp_stores<R>(lane, T, S * n, a.rampLines)) store_words<R>(tile + (size_t)T * cs, w);
+            }
             sw = false;
             if (jl >= n) { jl = 1; kl++; sw = kl < S; }
             else jl++;
@@ -392,7 +416,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 rcN = rp[(T_) + 1];                                                                                   \
                 e0N = edge[min((T_) + 2, n + 1)];                                                                     \
                 lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, (T_), lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
-                                                           hasNext, tile + (size_t)(T_) * cs, storeLanes);           \
+                                                           hasNext, tile + (size_t)(T_) * cs, storeLanes, a.rampLines); \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
             const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
@@ -924,8 +948,11 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
             } else {
                 acc[g % G] = pack_lo16(st.Hl[0], st.Hl[1]);
             }
-            if ((g % G) == G - 1 && t - (G - 1) < n + 63) { /* whole chunks, also on the skew ramps (see lin_step); nothing past the last step */
-                if (lane < storeLanes) {
+            if ((g % G) == G - 1 && t - (G - 1) < n + 63) { /* whole lines, also on the skew ramps (see lin_step); nothing past the last step */
+                /* (no ramp_stores() here: this kernel runs small batches, which are bound by the latency of a step, not by bytes --
+                 * line-rounded ramp masks measured 8 % SLOWER on 1000 x 512 x 512, tools/ab_ramp.sh) */
+                const bool doStore = lane < storeLanes;
+                if (doStore) {
                     u32x4 v = {acc[0], acc[1], acc[2], acc[3]};
                     stream_store(reinterpret_cast<u32x4 *>(tile + (size_t)(t / G) * cs), v);
                 }
@@ -1029,7 +1056,7 @@ template <int R, bool LOCAL, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                         const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP, const uint32_t e0,
                                         const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB,
-                                        const int storeLanes) {
+                                        const int storeLanes, const int rampLines) {
     const int j = t - lane + 1;
     const uint32_t upin = (uint32_t)wave_shr1((int)st.Hl[R - 1], (int)e0);
     bool active = true;
@@ -1065,7 +1092,9 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
         if constexpr (MASKED && !WHOLE) store_tile_pk<R>(tileA, tileB, st.Hl);
     }
     if constexpr (!MASKED || WHOLE) {
-        if (lane < storeLanes) store_tile_pk<R>(tileA, tileB, st.Hl); /* whole chunks (see lin_step) */
+        bool doStore = lane < storeLanes; /* whole lines (see lin_step) */
+        if constexpr (MASKED) doStore = doStore && ramp_stores<R>(lane, t, n, rampLines);
+        if (doStore) store_tile_pk<R>(tileA, tileB, st.Hl);
     }
 }
 
@@ -1139,7 +1168,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
             e0N = edge[min(t + 2, n + 1)];                                                                            \
             const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u); /* {A char, B char} -> 16-bit lanes */  \
             pk_step<R, LOCAL, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext, \
-                                       tileA + (size_t)t * csA, tileB + (size_t)t * csB, storeLanes);                \
+                                       tileA + (size_t)t * csA, tileB + (size_t)t * csB, storeLanes, a.rampLines);   \
         }
         const bool fast = (base + 64 * R <= m) && (n >= 64);
         const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;
@@ -1235,7 +1264,7 @@ template <int R, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
                                          const int match, const int mismatch, const int oe, const int e, const int e0H,
                                          const int e0D, const int rc, int16_t *edgeH, int16_t *edgeD,
-                                         const bool writeEdge, int16_t *tileDst, const int storeLanes) {
+                                         const bool writeEdge, int16_t *tileDst, const int storeLanes, const int rampLines) {
     const int j = t - lane + 1;
     const int upH = wave_shr1(st.Hl[R - 1], e0H);
     const int upD = wave_shr1(st.Dl[R - 1], e0D);
@@ -1253,8 +1282,10 @@ __device__ __forceinline__ void aff_step(AffState<R> &st, const int t, const int
             store_tile<R>(tileDst + 128 * R, st.Dl);
         }
     }
-    if constexpr (STORE && (!MASKED || WHOLE)) { /* whole chunks, also on the skew ramps (see lin_step) */
-        if (lane < storeLanes) {
+    if constexpr (STORE && (!MASKED || WHOLE)) { /* whole lines, also on the skew ramps (see lin_step) */
+        bool doStore = lane < storeLanes;
+        if constexpr (MASKED) doStore = doStore && ramp_stores<R>(lane, t, n, rampLines);
+        if (doStore) {
             store_tile<R>(tileDst, st.Hl);
             store_tile<R>(tileDst + 64 * R, st.Il);
             store_tile<R>(tileDst + 128 * R, st.Dl);
@@ -1349,10 +1380,12 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
                 }
             }
             if constexpr (STORE) {
-                int16_t *dst = tile + (size_t)T * cs;
-                store_tile<R>(dst, st.Hl);
-                store_tile<R>(dst + 64 * R, st.Il);
-                store_tile<R>(dst + 128 * R, st.Dl);
+                if (ramp_stores<R>(lane, T, S * n, a.rampLines)) { /* on the pair's two ramps only the lines with cells */
+                    int16_t *dst = tile + (size_t)T * cs;
+                    store_tile<R>(dst, st.Hl);
+                    store_tile<R>(dst + 64 * R, st.Il);
+                    store_tile<R>(dst + 128 * R, st.Dl);
+                }
             }
             sw = false;
             if (jl >= n) { jl = 1; kl++; sw = kl < S; }
@@ -1393,7 +1426,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
                 eHN = edgeH[min(t + 2, n + 1)];                                                                           \
                 eDN = k == 0 ? DPX_NEG : (int)edgeD[min(t + 2, n + 1)];                                                   \
                 aff_step<R, STORE, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, match, mismatch, oe, e, eH, eD, rc, edgeH, edgeD, \
-                                            hasNext, tile + (size_t)t * cs, storeLanes);                                  \
+                                            hasNext, tile + (size_t)t * cs, storeLanes, a.rampLines);                     \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
             const int storeLanes = (S == 1) ? store_lanes<R>(m) : 64;

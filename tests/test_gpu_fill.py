@@ -10,6 +10,19 @@ from dpx_gpu_genomics_project_amd.synth import from_strings, make_batch, make_ra
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["default", "one-wave-per-pair", "one-wave-per-pair+ramp-lines"])
+def kernel_path(request, monkeypatch):
+    """Every test of this file runs three times: with the engine's own choice (small multi-stripe batches take the split
+    kernel), with DPX_SPLIT=0 (the one-wave-per-pair kernels incl. their rolling multi-stripe schedule), and with the
+    line-rounded ramp stores big batches use (DPX_RAMP_LINES=1) forced onto these small ones."""
+    if request.param != "default":
+        monkeypatch.setenv("DPX_SPLIT", "0")
+    if request.param.endswith("ramp-lines"):
+        monkeypatch.setenv("DPX_RAMP_LINES", "1")
+    return request.param
+
+
 HAND = [("0", "0"), ("0", "1"), ("0123", "0"), ("3", "0123"), ("00000000", "00000000"), ("01230123", "32103210"),
         ("ABxxxCDE", "ABCDE"), ("GTCATGCAATAACG", "ATGCAATA"), ("GTCAGTA", "ATACA"), ("4444", "4444"), ("0404", "4040"),
         ("", "0123"), ("0123", ""), ("", "")]

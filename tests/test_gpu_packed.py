@@ -9,6 +9,15 @@ from dpx_gpu_genomics_project_amd.synth import from_strings, make_batch, make_ra
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["whole-ramp-chunks", "ramp-lines"])
+def ramp_mode(request, monkeypatch):
+    """Small test batches store whole chunks on the skew ramps; batches of >= 2048 pairs store only the lines that hold cells
+    (DPX_RAMP_LINES=1 forces that here): both, for every test of this file."""
+    if request.param == "ramp-lines":
+        monkeypatch.setenv("DPX_RAMP_LINES", "1")
+    return request.param
+
+
 def _check(dpx, algo, sb, w, every=1):
     code = {"LNW": dpx.ALGO_LNW, "LSW": dpx.ALGO_LSW}[algo]
     with dpx.Batch(code, sb.sequences, sb.pairs, *w) as b:
