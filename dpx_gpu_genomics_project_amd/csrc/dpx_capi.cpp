@@ -715,18 +715,20 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         if (b->quad) lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
         else { b->R = R; singles.clear(); }
     }
-    bool usePacked = !b->quad && b->store && linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1 &&
+    bool usePacked = !b->quad && b->store && ((linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1) || banded) &&
                      numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
     if (b->quad) usePacked = false;
     else
-    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW);
+    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (linearAlgo || banded);
     /* 16-bit wrapping arithmetic: only when weights and every intermediate provably fit (also under DPX_PACKED=1) */
     if (usePacked) {
         dpx_params kp = *params;
         kp.algo = kernelAlgo;
         usePacked = packed_safe(kp, b->maxM, b->maxN);
-        /* 4-byte edge entries + 2-byte reference entries per wave: very long references do not fit the LDS twice over */
-        const size_t pkNeed = (align_up((size_t)(b->maxN + 2) * 4, 16) + align_up(((size_t)b->maxN + 128) * 2, 16)) * (DPX_FILL_THREADS / 64);
+        /* 4-byte edge entries + 2-byte reference entries per wave: very long references do not fit the LDS twice over
+         * (band kernel: 2-byte query and reference entries) */
+        const size_t pkNeed = (banded ? align_up(((size_t)b->maxM + 96) * 2, 16) + align_up(((size_t)b->maxN + 32) * 2, 16)
+                                      : align_up((size_t)(b->maxN + 2) * 4, 16) + align_up(((size_t)b->maxN + 128) * 2, 16)) * (DPX_FILL_THREADS / 64);
         if (pkNeed > 160u * 1024u) usePacked = false;
     }
     if (usePacked) {
@@ -984,7 +986,16 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), kLdsFloor);
         if (b->streamLds > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
+    if (b->packed && banded) { /* packed band kernel: 2-byte query and reference entries (two chars each) */
+        dpx_fill_args &k = b->pkArgs;
+        k = a;
+        k.order = b->dCouples;
+        k.numPairs = (int32_t)numCouples;
+        const size_t q2 = align_up(((size_t)b->maxM + 96) * 2, 16), r2 = align_up(((size_t)b->maxN + 32) * 2, 16);
+        k.ldsPerWave = (uint32_t)(q2 + r2);
+        k.ldsRefOff = (uint32_t)q2;
+        b->pkLdsBytes = (q2 + r2) * (DPX_FILL_THREADS / 64);
+    } else if (b->packed) { /* packed kernel: 4-byte edge entries (two int16), 2-byte reference entries (two chars) */
         dpx_fill_args &k = b->pkArgs;
         k = a;
         k.order = b->dCouples;
@@ -1048,7 +1059,8 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
         if (e == hipSuccess) e = dpx_launch_fill_lanes(b->pkArgs, b->kernelAlgo, b->R, b->store, b->pkLdsBytes, s);
     } else if (b->packed) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
-        if (e == hipSuccess) e = dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+        if (e == hipSuccess) e = b->kernelAlgo == DPX_ALGO_BSW ? dpx_launch_banded_packed(b->pkArgs, b->R, b->pkLdsBytes, s)
+                                                               : dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
     } else if (b->split) {
         e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, s);
     } else if (b->streamed) {
@@ -1325,7 +1337,7 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
 int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
-    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? "k_banded_fill" : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_lanes" : "k_affine_fill")
+    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_lanes" : "k_affine_fill")
                          : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d",

@@ -1736,6 +1736,194 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
 }
 
 /* =====================================================================================================
+ * "+Opt" for the band: two equal-shaped pairs per wave, pair A in the high and pair B in the low half of every register,
+ * the cell update on the packed-int16 pipe as in k_linear_fill_pk (the reference's V18/V19 idea, cuda/LNW/
+ * LinearNeedlemanWunschV18.cu:112-341), the anti-diagonal schedule of k_banded_fill unchanged: one DPP move carries both
+ * pairs' neighbour cell, the per-lane in-band masks and the head / tail window tests are the same for both (same shape).
+ * The one-pair kernel needs ~36 vector instructions per step for its 2 cells per lane (band 128) and sits between the
+ * VALU and the write limit; two pairs per instruction leave it to the stores.  SW start cell per half: packed running
+ * maximum + the step at which it was first reached (5 packed ops per slot and step, see PkState).
+ * ===================================================================================================== */
+template <int C>
+struct BandStatePk {
+    uint32_t prev[C], prev2[C]; /* anti-diagonals a-1 and a-2, {A, B} */
+    uint32_t qch[C], rch[C];    /* query / reference characters in 16-bit lanes, {A, B} */
+    uint32_t rmax[C], rstep[C]; /* per slot: running maximum and the step it was first reached, {A, B} */
+    uint32_t inBand[2][C];      /* ~0 / 0: is slot s inside the band on a step of parity p (s <= B-1-p)? */
+};
+
+__device__ __forceinline__ uint32_t pk_chars(const uint16_t both) { return __builtin_amdgcn_perm(0u, (uint32_t)both, 0x0c010c00u); } /* A<<8|B -> {A, B} */
+
+template <int C, bool P1, bool INTERIOR>
+__device__ __forceinline__ void band_step_pk(BandStatePk<C> &st, const int A, int &i0, int &j0, const int lane, const int m, const int n,
+                                             const int B, const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP,
+                                             const uint16_t *qL, const uint16_t *rL, uint32_t *out) {
+    const int p = P1 ? 1 : 0;
+    if constexpr (P1) i0++; else j0++;
+    const int smin = INTERIOR ? 0 : max(max(1 - i0, j0 - n), 0);
+    const int smax = INTERIOR ? 0 : min(min(m - i0, j0 - 1), B - 1 - p);
+    uint32_t up[C], left[C];
+    if constexpr (P1) {
+        const uint32_t newq = pk_chars(INTERIOR ? qL[i0 + 64 * C - 2] : qL[min(max(i0 + 64 * C - 2, 0), m - 1)]);
+        const uint32_t tq = (uint32_t)wave_shl1((int)st.qch[0], (int)newq);
+#pragma unroll
+        for (int c = 0; c < C - 1; c++) st.qch[c] = st.qch[c + 1];
+        st.qch[C - 1] = tq;
+        const uint32_t nb = (uint32_t)wave_shl1((int)st.prev[0], 0);
+#pragma unroll
+        for (int c = 0; c < C; c++) { up[c] = st.prev[c]; left[c] = (c < C - 1) ? st.prev[c + 1] : nb; }
+    } else {
+        const uint32_t newr = pk_chars(INTERIOR ? rL[j0 - 1] : rL[min(max(j0 - 1, 0), n - 1)]);
+        const uint32_t tr = (uint32_t)wave_shr1((int)st.rch[C - 1], (int)newr);
+#pragma unroll
+        for (int c = C - 1; c > 0; c--) st.rch[c] = st.rch[c - 1];
+        st.rch[0] = tr;
+        const uint32_t nb = (uint32_t)wave_shr1((int)st.prev[C - 1], 0);
+#pragma unroll
+        for (int c = 0; c < C; c++) { left[c] = st.prev[c]; up[c] = (c > 0) ? st.prev[c - 1] : nb; }
+    }
+    const uint32_t onesP = 0x00010001u;
+    const uint32_t stepP = ((uint32_t)A << 16) | (uint32_t)A;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t differs = dpx::pk_min_u16_raw(st.qch[c] ^ st.rch[c], onesP);
+        const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));
+        const s16x2 g = dpx::pk_max(as_s16x2(up[c]), as_s16x2(left[c])) + as_s16x2(gapP);
+        uint32_t h = as_u32(dpx::pk_max(dpx::pk_max(g, (s16x2)(as_s16x2(st.prev2[c]) + sc)), as_s16x2(0u)));
+        if constexpr (INTERIOR) {
+            h &= st.inBand[P1 ? 1 : 0][c];
+        } else {
+            const int s = lane * C + c;
+            h = ((s >= smin) && (s <= smax)) ? h : 0u;
+        }
+        const uint32_t nm = dpx::pk_max_u16_raw(st.rmax[c], h);
+        const uint32_t grew = dpx::pk_min_u16_raw(dpx::pk_sub_u16_raw(nm, st.rmax[c]), onesP);
+        st.rstep[c] = dpx::bfi_b32(dpx::pk_sub_u16_raw(0u, grew), stepP, st.rstep[c]);
+        st.rmax[c] = nm;
+        st.prev2[c] = st.prev[c];
+        st.prev[c] = h;
+        out[c] = h;
+    }
+}
+
+template <int C, bool PB>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill_pk(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int G = (C >= 8) ? 1 : 8 / C;
+    constexpr int GG = (G < 2) ? 2 : G;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cpl = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* couple index */
+    if (cpl >= a.numPairs) return;
+    const int pA = a.order[2 * cpl], pB = a.order[2 * cpl + 1];
+    const dpx_pair_dev prA = a.pairs[pA], prB = a.pairs[pB];
+    const int n = prA.n, m = prA.m, B = a.band; /* host guarantees equal shapes, both > 0 */
+    const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
+    const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
+    const uint32_t gapP = ((uint32_t)(uint16_t)a.gapOpen << 16) | (uint16_t)a.gapOpen;
+    const unsigned char *refA = reinterpret_cast<const unsigned char *>(a.seq + prA.refIdx), *refB = reinterpret_cast<const unsigned char *>(a.seq + prB.refIdx);
+    const unsigned char *qryA = reinterpret_cast<const unsigned char *>(a.seq + prA.qryIdx), *qryB = reinterpret_cast<const unsigned char *>(a.seq + prB.qryIdx);
+    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
+    uint16_t *qL = reinterpret_cast<uint16_t *>(my);               /* entry i: query A char << 8 | query B char */
+    uint16_t *rL = reinterpret_cast<uint16_t *>(my + a.ldsRefOff); /* entry j: reference A char << 8 | reference B char */
+    auto stage2 = [&](uint16_t *dst, const unsigned char *sa, const unsigned char *sb, const int len) {
+        for (int x = 4 * lane; x < len; x += 256) { /* four entries per lane and trip (see k_linear_fill_pk) */
+            const uint32_t a4 = load4(sa + x), b4 = load4(sb + x);
+            uint2 w;
+            w.x = __builtin_amdgcn_perm(a4, b4, 0x05010400u);
+            w.y = __builtin_amdgcn_perm(a4, b4, 0x07030602u);
+            *reinterpret_cast<uint2 *>(dst + x) = w;
+        }
+    };
+    stage2(qL, qryA, qryB, m);
+    stage2(rL, refA, refB, n);
+
+    BandStatePk<C> st;
+    {
+        const int p1 = B & 1;
+        const int i0 = (1 + p1 - (B - 1)) >> 1;
+        const int j0 = 1 - i0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int s = lane * C + c;
+            st.qch[c] = pk_chars(qL[min(max(i0 + s - 1, 0), m - 1)]);
+            st.rch[c] = pk_chars(rL[min(max(j0 - s - 1, 0), n - 1)]);
+            st.prev[c] = 0u; st.prev2[c] = 0u; st.rmax[c] = 0u; st.rstep[c] = 0u;
+            st.inBand[0][c] = (s <= B - 1) ? ~0u : 0u;
+            st.inBand[1][c] = (s <= B - 2) ? ~0u : 0u;
+        }
+    }
+    auto interior = [&](const int A) -> bool {
+        const int aa = A + 2, pp = (aa + B - 1) & 1;
+        const int i0 = (aa + pp - (B - 1)) >> 1, j0 = aa - i0, top = B - 1 - pp;
+        return i0 >= 1 && i0 + top <= m && j0 - top >= 1 && j0 <= n;
+    };
+    const int NS = m + n - 1;
+    const int numGroups = (NS + G - 1) / G;
+    int16_t *HpA = a.mat + prA.matOff + (size_t)lane * 8u, *HpB = a.mat + prB.matOff + (size_t)lane * 8u;
+    const size_t csA = prA.chunkStride, csB = prB.chunkStride;
+    uint32_t acc[8];
+    int i0 = (1 + (B & 1) - (B - 1)) >> 1;
+    int j0 = 1 - i0;
+    auto store_group = [&](const int grp) {
+        uint4 va, vb;
+        va.x = pk_hi16(acc[0], acc[1]); va.y = pk_hi16(acc[2], acc[3]); va.z = pk_hi16(acc[4], acc[5]); va.w = pk_hi16(acc[6], acc[7]);
+        vb.x = pack_lo16((int)acc[0], (int)acc[1]); vb.y = pack_lo16((int)acc[2], (int)acc[3]);
+        vb.z = pack_lo16((int)acc[4], (int)acc[5]); vb.w = pack_lo16((int)acc[6], (int)acc[7]);
+        *reinterpret_cast<uint4 *>(HpA + (size_t)grp * csA) = va;
+        *reinterpret_cast<uint4 *>(HpB + (size_t)grp * csB) = vb;
+    };
+#define DPX_BANDPK_BODY(INTERIOR_)                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < GG; g += 2) {                                                                    \
+        band_step_pk<C, PB, INTERIOR_>(st, A0 + g, i0, j0, lane, m, n, B, matchP, negDeltaP, gapP, qL, rL, &acc[(g % G) * C]); \
+        if constexpr (G == 1) {                                                                                             \
+            if (INTERIOR_ || A0 + g < numGroups) store_group(A0 + g);                                                      \
+        }                                                                                                                   \
+        band_step_pk<C, !PB, INTERIOR_>(st, A0 + g + 1, i0, j0, lane, m, n, B, matchP, negDeltaP, gapP, qL, rL,             \
+                                        &acc[((g + 1) % G) * C]);                                                           \
+        if (((g + 1) % G) == G - 1) {                                                                                       \
+            const int grp = (A0 + g + 1) / G;                                                                               \
+            if (INTERIOR_ || grp < numGroups) store_group(grp);                                                            \
+        }                                                                                                                   \
+    }
+    int A0 = 0;
+    for (; A0 < NS && !(interior(A0) && interior(A0 + GG - 1)); A0 += GG) { DPX_BANDPK_BODY(false) }
+    for (; A0 + GG <= NS && interior(A0 + GG - 1); A0 += GG) { DPX_BANDPK_BODY(true) }
+    for (; A0 < NS; A0 += GG) { DPX_BANDPK_BODY(false) }
+#undef DPX_BANDPK_BODY
+    /* candidates per half: every slot's first maximum; rows / columns recovered from (step, slot) as in k_banded_fill */
+    unsigned long long mine[2] = {0ull, 0ull};
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int hv = half ? (int)(st.rmax[c] & 0xFFFFu) : (int)(st.rmax[c] >> 16);
+            if (hv > 0) {
+                const int A = half ? (int)(st.rstep[c] & 0xFFFFu) : (int)(st.rstep[c] >> 16);
+                const int aa = A + 2;
+                const int pp = (aa + B - 1) & 1;
+                const int u = 2 * (lane * C + c) + pp;
+                const int i = (aa + u - (B - 1)) >> 1;
+                const int j = aa - i;
+                const unsigned long long k = ((unsigned long long)(unsigned)hv << 40) | ((unsigned long long)(0xFFFFFu - (unsigned)i) << 20) |
+                                             (unsigned long long)(0xFFFFFu - (unsigned)j);
+                mine[half] = k > mine[half] ? k : mine[half];
+            }
+        }
+    }
+    const unsigned long long topA = wave_max_u64(mine[0]), topB = wave_max_u64(mine[1]);
+    if (lane == 0) {
+        const int hA = (int)(topA >> 40), hB = (int)(topB >> 40);
+        a.score[pA] = hA;
+        a.endRow[pA] = hA > 0 ? (int)(0xFFFFFu - (unsigned)((topA >> 20) & 0xFFFFFu)) : 0;
+        a.endCol[pA] = hA > 0 ? (int)(0xFFFFFu - (unsigned)(topA & 0xFFFFFu)) : 0;
+        a.score[pB] = hB;
+        a.endRow[pB] = hB > 0 ? (int)(0xFFFFFu - (unsigned)((topB >> 20) & 0xFFFFFu)) : 0;
+        a.endCol[pB] = hB > 0 ? (int)(0xFFFFFu - (unsigned)(topB & 0xFFFFFu)) : 0;
+    }
+}
+
+/* =====================================================================================================
  * Export: un-tile one pair's plane into the reference's row-major (m+1) x (n+1) layout, borders included.
  * ===================================================================================================== */
 __global__ void k_export_matrix(const int16_t *mat, dpx_pair_dev pr, int algo, int R, int planes, int plane, int gapOpen,
@@ -2344,7 +2532,25 @@ hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_
     }
 }
 
-/* SW start-cell completion for pairs filled by a row-maxima kernel; a.order / a.numPairs select the pairs */
+/* packed banded fill: a.order = couples (2 ints each), a.numPairs = number of couples; C = cells per lane */
+template <int C>
+static hipError_t launch_banded_pk_C(const dpx_fill_args &a, dim3 grid, size_t lds, hipStream_t s) {
+    const bool pb = ((a.band + 1) & 1) != 0; /* parity of step A = 0 */
+    return pb ? launch_fill_kernel(k_banded_fill_pk<C, true>, a, grid, lds, s) : launch_fill_kernel(k_banded_fill_pk<C, false>, a, grid, lds, s);
+}
+hipError_t dpx_launch_banded_packed(const dpx_fill_args &a, int C, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
+    switch (C) {
+    case 1: return launch_banded_pk_C<1>(a, grid, ldsBytes, stream);
+    case 2: return launch_banded_pk_C<2>(a, grid, ldsBytes, stream);
+    case 4: return launch_banded_pk_C<4>(a, grid, ldsBytes, stream);
+    case 8: return launch_banded_pk_C<8>(a, grid, ldsBytes, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream) {

@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(autouse=True, params=["one-pair-per-wave", "packed"])
+def kernel_path(request, monkeypatch):
+    """Every test of this file twice: on k_banded_fill, and with DPX_PACKED=1 on k_banded_fill_pk (two equal-shaped pairs per
+    wave on the packed-int16 pipe; odd pairs out and other shapes fall back to the one-pair kernel inside the same batch)."""
+    if request.param == "packed":
+        monkeypatch.setenv("DPX_PACKED", "1")
+    return request.param
+
+
 def crc(a):
     return zlib.crc32(np.ascontiguousarray(a, dtype="<i4").tobytes()) & 0xFFFFFFFF
 
@@ -84,3 +93,23 @@ def test_algorithmic_bytes_count_the_in_band_cells(gpu):
             want = sum(2 * (int(r["querySize"]) + 1) * (int(r["referenceSize"]) + 1) + int(r["querySize"]) + int(r["referenceSize"]) + 28 for r in sb.pairs)
         with gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=band) as b:
             assert b.info()["algorithmic_bytes"] == want, band
+
+
+def test_packed_band_kernel_is_taken_and_survives_fuzz_weights(gpu, kernel_path):
+    rng = np.random.default_rng(77)
+    for band, m, n, w in ((128, 700, 650, (3, -1, -2)), (31, 200, 333, (5, 2, -4)), (300, 512, 512, (1, -2, 1)), (64, 90, 400, (2, -3, 0)), (9, 50, 50, (0, 0, 0))):
+        alphabet = np.array([48, 49, 50, 51], np.uint8) if w[0] == 3 else np.arange(256, dtype=np.uint8)
+        pairs = []
+        for _ in range(5):
+            ref = rng.choice(alphabet, size=n).astype(np.uint8)
+            q = np.resize(ref, m).copy()
+            flip = rng.random(m) < 0.2
+            q[flip] = rng.choice(alphabet, size=int(flip.sum()))
+            pairs.append((ref.tobytes(), q.tobytes()))
+        sb = from_strings(pairs)
+        with gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, *w, band=band) as b:
+            d = b.describe()
+            assert d["kernel"] == ("k_banded_fill_pk" if kernel_path == "packed" else "k_banded_fill"), d
+            if kernel_path == "packed":
+                assert d["couples"] == 2 and d["singles"] == 1
+        _check(gpu, sb, band, w)
