@@ -912,12 +912,18 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
                 off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
             }
         } else if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave = two adjacent slots */
-        else if (b->quad) { /* 8 x 8 tile layout (dpx_layout.h): every pair a contiguous run of whole 128-byte lines, in launch order */
-            for (int32_t c : couples) {
-                dpx_pair_dev &pd = b->pairs[c];
-                pd.matOff = off;
-                pd.chunkStride = dpx_tile8_chunk_elems(pd.m, b->planes);
-                off += dpx_tile8_col_blocks(pd.m, pd.n) * (uint64_t)pd.chunkStride;
+        else if (b->quad) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
+            const uint32_t stepElems = dpx_wtile_step_elems(b->R / 8, b->planes);
+            for (const dpx_wave_desc &wd : waves) {
+                uint64_t steps = 0;
+                for (int k = 0; k < DPX_WAVE_SLOTS; k++) {
+                    if (!wd.num[k]) continue;
+                    dpx_pair_dev &pd = b->pairs[wd.pair[k]];
+                    pd.matOff = off;
+                    pd.chunkStride = wd.first[k];
+                    steps = std::max(steps, dpx_wtile_steps(pd.m, pd.n, b->R, wd.first[k]));
+                }
+                off += steps * (uint64_t)stepElems;
             }
         }
         if (b->streamed) {

@@ -500,18 +500,15 @@ constexpr int kLaneScratch = 1024; /* per wave: 16 B per lane for the end-of-pai
 template <int Q, int PLANES>
 struct LineStage {
     static constexpr int kBytes = PLANES * Q * 64 * kStageLine; /* per wave */
+    static constexpr int kStepElems = PLANES * Q * 512;         /* int16 elements a wave stores per step (dpx_layout.h) */
     u32x4 pend[PLANES * Q];
-    int16_t *pendDst = nullptr; /* line of (plane 0, sub-tile 0); plane p, sub-tile h: + (p*LB + h)*64 elements */
-    uint32_t pendLB = 0;
+    int16_t *pendDst = nullptr; /* this lane's 16 bytes of (plane 0, sub-tile 0) in the step's chunk; plane p, sub-tile h: + (p*Q + h)*512 elements */
     int pendN = 0;              /* sub-tiles of the owner lane that hold rows (0: nothing to store) */
-    u32x4 route;                /* routing record of the owner whose lines complete in the NEXT step */
+    uint32_t route = 0;         /* routing word of the owner whose lines complete in the NEXT step */
 
-    /* routing record of a lane, written once: {line pointer lo, hi, column-block stride (elements), skew | n8 << 8 | valid sub-tiles << 24 | LB << 26 ...} */
-    static __device__ __forceinline__ void set_route(unsigned char *tile, int lane, const int16_t *line0, uint32_t cs, int skew, int n8,
-                                                     int nValid, uint32_t LB) {
-        const uintptr_t ptr = reinterpret_cast<uintptr_t>(line0);
-        u32x4 r = {(uint32_t)ptr, (uint32_t)(ptr >> 32), cs | (LB << 20), (uint32_t)skew | ((uint32_t)n8 << 8) | ((uint32_t)nValid << 28)};
-        *reinterpret_cast<u32x4 *>(tile + lane * kStageLine + 128) = r;
+    /* routing word of a lane, written once into the 16 spare bytes of its LDS line: skew | n8 << 8 | valid sub-tiles << 28 */
+    static __device__ __forceinline__ void set_route(unsigned char *tile, int lane, int skew, int n8, int nValid) {
+        *reinterpret_cast<uint32_t *>(tile + lane * kStageLine + 128) = (uint32_t)skew | ((uint32_t)n8 << 8) | ((uint32_t)nValid << 28);
     }
     /* park the lane's 8 rows of sub-tile h, plane p, in slot t % 8 of its line (t = the wave's step) */
     static __device__ __forceinline__ void put(unsigned char *tile, int lane, int p, int h, int t, u32x4 v) {
@@ -529,24 +526,22 @@ struct LineStage {
         for (int h = 0; h < Q; h++) {
             if (h < pendN) {
 #pragma unroll
-                for (int p = 0; p < PLANES; p++) stream_store(reinterpret_cast<u32x4 *>(pendDst + ((size_t)(p * pendLB + h) << 6)), pend[p * Q + h]);
+                for (int p = 0; p < PLANES; p++) stream_store(reinterpret_cast<u32x4 *>(pendDst + ((p * Q + h) << 9)), pend[p * Q + h]);
             }
         }
     }
     __device__ __forceinline__ void fetch_route(const unsigned char *tile, int lane, int tNext) {
-        route = *reinterpret_cast<const u32x4 *>(tile + ((lane & ~7) | ((tNext + 1) & 7)) * kStageLine + 128);
+        route = *reinterpret_cast<const uint32_t *>(tile + ((lane & ~7) | ((tNext + 1) & 7)) * kStageLine + 128);
     }
-    /* step t: read piece lane%8 of the lines that completed in this step (owner = lane (t+1)%8 of this lane's 8-group),
-     * routed by the record fetch_route(t) brought in during the previous step */
-    __device__ __forceinline__ void fetch(const unsigned char *tile, int lane, int t) {
+    /* step t: read piece lane%8 of the lines that completed in this step (owner = lane (t+1)%8 of this lane's 8-group), valid
+     * if the owner's column t + 1 - skew is one of its column-block ends (routing word fetched during the previous step);
+     * they go to chunk t of the wave's stream, at this lane's 16 bytes */
+    __device__ __forceinline__ void fetch(const unsigned char *tile, int16_t *waveBase, int lane, int t) {
         const int owner = (lane & ~7) | ((t + 1) & 7);
-        const int jg = t + 1 - (int)(route.w & 0xFFu);           /* owner's column: a multiple of 8 */
-        const int n8 = (int)((route.w >> 8) & 0xFFFFFu);
-        const bool ok = jg >= 8 && jg <= n8;
-        int16_t *line0 = reinterpret_cast<int16_t *>((uintptr_t)route.x | ((uintptr_t)route.y << 32));
-        pendDst = line0 + (size_t)((jg >> 3) - 1) * (size_t)(route.z & 0xFFFFFu) + ((lane & 7) << 3);
-        pendLB = route.z >> 20;
-        pendN = ok ? (int)(route.w >> 28) : 0;
+        const int jg = t + 1 - (int)(route & 0xFFu); /* owner's column: a multiple of 8 */
+        const int n8 = (int)((route >> 8) & 0xFFFFFu);
+        pendN = (jg >= 8 && jg <= n8) ? (int)(route >> 28) : 0;
+        pendDst = waveBase + (size_t)t * kStepElems + (lane << 3);
 #pragma unroll
         for (int p = 0; p < PLANES; p++)
 #pragma unroll
@@ -618,9 +613,11 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
 
     const int skew = l + sl.d; /* this lane runs column j = t - skew + 1 in step t */
     const int n8 = (n + 7) & ~7;
-    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
-    if constexpr (STORE)
-        Stage::set_route(tileL, lane, a.mat + pr.matOff + ((size_t)(l * Q) << 6), cs, skew, n8, has ? min(max((int)LB - l * Q, 0), Q) : 0, LB);
+    const int LB = (int)dpx_tile8_row_blocks(m);
+    if constexpr (STORE) Stage::set_route(tileL, lane, skew, n8, has ? min(max(LB - l * Q, 0), Q) : 0);
+    /* the wave's stream of chunks (dpx_layout.h): every pair of the wave carries the same base; lane 0 always belongs to slot 0 */
+    int16_t *waveBase = a.mat + (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff & 0xFFFFFFFFull)));
     const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
     const unsigned char *rp = refs - skew; /* rp[t] = reference character of column j = t - skew + 1 */
     int rcN = rp[0];
@@ -645,7 +642,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
                 }
             }
             stage.store();
-            stage.fetch(tileL, lane, t);
+            stage.fetch(tileL, waveBase, lane, t);
             stage.fetch_route(tileL, lane, t + 1);
         }
     };
@@ -1506,9 +1503,10 @@ __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_f
 
     const int skew = l + sl.d;
     const int n8 = (n + 7) & ~7;
-    const uint32_t cs = pr.chunkStride, LB = dpx_tile8_row_blocks(m);
-    if constexpr (STORE)
-        Stage::set_route(tileL, lane, a.mat + pr.matOff + ((size_t)(l * Q) << 6), cs, skew, n8, has ? min(max((int)LB - l * Q, 0), Q) : 0, LB);
+    const int LB = (int)dpx_tile8_row_blocks(m);
+    if constexpr (STORE) Stage::set_route(tileL, lane, skew, n8, has ? min(max(LB - l * Q, 0), Q) : 0);
+    int16_t *waveBase = a.mat + (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff & 0xFFFFFFFFull)));
     const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
     const unsigned char *rp = refs - skew;
     int rcN = rp[0];
@@ -1537,7 +1535,7 @@ __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_f
                 }
             }
             stage.store();
-            stage.fetch(tileL, lane, t);
+            stage.fetch(tileL, waveBase, lane, t);
             stage.fetch_route(tileL, lane, t + 1);
         }
     };
@@ -2012,9 +2010,8 @@ struct TileWalker {
     __device__ __forceinline__ u32x4 column(int i0, int jj) const { /* the 8-row group of row i0 (0-based), column jj >= 1 */
         const int r = i0 & ((1 << sr) - 1), sub = r >> 3;
         uint64_t T, tile;
-        if (lanes == 16) { /* 8 x 8 tile layout: the column's 8 rows are one 16-byte piece of the row block's line */
-            T = (uint64_t)((jj - 1) >> 3);
-            tile = (uint64_t)(((i0 >> 3) << 6) + (((jj - 1) & 7) << 3));
+        if (lanes == 16) { /* tile layout: the column's 8 rows are one 16-byte piece of a line of the wave's stream (cs = first lane) */
+            return *reinterpret_cast<const u32x4 *>(mat + off + (dpx_wtile_index(i0 + 1, jj, 0, 1, 1 << sr, cs) & ~(uint64_t)7));
         } else {
             const int k = i0 >> (sr + 6), l = (i0 >> sr) & 63;
             T = (uint64_t)k * (uint64_t)n + (uint64_t)(jj - 1) + (uint64_t)l;

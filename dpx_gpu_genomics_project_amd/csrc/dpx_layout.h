@@ -80,24 +80,36 @@ DPX_HD uint32_t dpx_tile_off(int R, int plane, int l, int r) {
     const int sq = R < 8 ? dpx_log2(R) : 3, Q = R >> sq; /* sub-tiles of 2^sq rows */
     return (uint32_t)(((((plane * Q + (r >> sq)) << 6) + l) << sq) + (r & ((1 << sq) - 1)));
 }
-/* Tile layout (pairs filled by the quad kernels, dpx_pair_dev.lanes == 16): the matrix is cut into 8 x 8 tiles, one
- * 128-byte line each, column-block-major, columns before rows inside the tile:
+/* Tile layout (pairs filled by the lane-packed kernels, dpx_pair_dev.lanes == 16): the matrix is cut into 8 x 8 tiles, one
+ * 128-byte line each (columns before rows inside the tile: the 8 rows of one column are 16 contiguous bytes -- what a lane
+ * produces per step -- and the 8 columns of a row block are one whole line -- what it has produced after 8 steps).  The lines
+ * are laid out as the WAVE produces them: a pair's lane l (rows [l*R, l*R+R), R = 8*Q) is lane lambda = first + l of a wave that
+ * aligns several pairs (dpx_wave_desc), runs column j in step t = j - 1 + skew with skew = l + (first & 7), and therefore
+ * completes column block cb = (j-1)/8 in step t = 8*(cb+1) + skew - 1 -- together with lanes lambda +- 8, +- 16 ... of the same
+ * wave, whatever pairs they belong to.  The eight lines of one step are stored side by side:
  *
- *       element(i, j, plane) = matOff + cb*chunkStride + (plane*LB + rb)*64 + c*8 + rr
- *       with rb = (i-1)/8, rr = (i-1)%8, cb = (j-1)/8, c = (j-1)%8, LB = ceil(m/8), chunkStride = planes*LB*64
+ *       element(i, j, plane) = matOff + t * (planes*Q*512) + (plane*Q + h) * 512 + (lambda >> 3) * 64 + c*8 + rr
+ *       l = (i-1)/R, h = ((i-1)%R)/8, rr = (i-1)%8, c = (j-1)%8, t and lambda as above; matOff = the WAVE's base (shared by its pairs),
+ *       chunkStride = first (the pair's first lane)
  *
- * so the 8 rows of one column inside a row block are 16 contiguous bytes (what a lane produces per step) and the 8
- * columns of a row block are one whole line (what a lane has produced after 8 steps).  Nothing depends on the wave's
- * skew: ceil(n/8) * ceil(m/8) lines per plane and pair, no ramp padding, rows rounded up to 8 instead of to the 64-row
- * height of a [lane][8 rows] line (a 104 x 130 pair: 28.3 KB stored for 27.5 KB algorithmic; the [step][lane][rows]
- * chunks of round 1 stored 37 KB).  The kernels transpose through LDS to get there, see k_linear_quad. */
+ * so every step of a wave is one contiguous 1-KiB store per plane and row-block half (as in the wavefront-tiled layout), but only
+ * lines that hold cells are ever written: no skew-ramp padding, rows rounded up to 8 instead of to the 64 / 128-row height of a
+ * [lane][rows] line (round 1's [step][lane][rows] chunks wrote 1.40x the algorithmic bytes on short reads; this writes 1.05x).
+ * The kernels transpose through LDS to get there, see k_linear_lanes. */
 DPX_HD uint32_t dpx_tile8_row_blocks(int m) { return (uint32_t)((m + 7) >> 3); }
-DPX_HD uint64_t dpx_tile8_col_blocks(int m, int n) { return (m <= 0 || n <= 0) ? 0 : (uint64_t)((n + 7) >> 3); }
-DPX_HD uint32_t dpx_tile8_chunk_elems(int m, int planes) { return (uint32_t)planes * dpx_tile8_row_blocks(m) * 64u; }
-DPX_HD uint64_t dpx_tile8_index(int i, int j, int plane, int planes, uint32_t chunkStride) {
-    const uint32_t LB = chunkStride / (64u * (uint32_t)planes);
-    const int i0 = i - 1, j0 = j - 1;
-    return (uint64_t)(j0 >> 3) * (uint64_t)chunkStride + (uint64_t)((((uint32_t)plane * LB + (uint32_t)(i0 >> 3)) << 6) + ((j0 & 7) << 3) + (i0 & 7));
+DPX_HD uint32_t dpx_wtile_step_elems(int Q, int planes) { return (uint32_t)(planes * Q * 512); }
+/* steps (1-KiB chunks per plane and half) the wave of this pair needs for it: its last column block completes in step n8 + skew - 1 */
+DPX_HD uint64_t dpx_wtile_steps(int m, int n, int R, int first) {
+    if (m <= 0 || n <= 0) return 0;
+    const int L = (m + R - 1) / R;
+    return (uint64_t)(((n + 7) & ~7) + (L - 1) + (first & 7));
+}
+DPX_HD uint64_t dpx_wtile_index(int i, int j, int plane, int planes, int R, uint32_t first) {
+    const int Q = R >> 3, i0 = i - 1, j0 = j - 1;
+    const int l = i0 / R, h = (i0 % R) >> 3;
+    const int lam = (int)first + l, skew = l + ((int)first & 7);
+    const uint64_t t = (uint64_t)(((j0 >> 3) + 1) * 8 + skew - 1);
+    return t * (uint64_t)dpx_wtile_step_elems(Q, planes) + (uint64_t)(((plane * Q + h) << 9) + ((lam >> 3) << 6) + ((j0 & 7) << 3) + (i0 & 7));
 }
 /* offset of cell (i, j) of `plane` relative to the pair's matOff */
 DPX_HD uint64_t dpx_tiled_index(int i, int j, int n, int R, int plane, uint32_t chunkStride) {
@@ -129,7 +141,7 @@ DPX_HD uint64_t dpx_split_index(int i, int j, int n, int R, uint32_t chunkStride
 /* either layout, by the pair's `lanes` tag */
 DPX_HD uint64_t dpx_cell_index(int i, int j, int n, int R, int plane, int planes, uint32_t chunkStride, uint32_t lanes) {
     if (lanes == 32) return dpx_split_index(i, j, n, R, chunkStride);
-    return lanes == 16 ? dpx_tile8_index(i, j, plane, planes, chunkStride) : dpx_tiled_index(i, j, n, R, plane, chunkStride);
+    return lanes == 16 ? dpx_wtile_index(i, j, plane, planes, R, chunkStride) : dpx_tiled_index(i, j, n, R, plane, chunkStride);
 }
 
 /*
