@@ -764,7 +764,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     {
         bool anyEmpty = false;
         for (size_t i = 0; i < numPairs && !anyEmpty; i++) anyEmpty = b->pairs[i].m <= 0 || b->pairs[i].n <= 0;
-        const int sR = b->maxM > 4096 ? 8 : b->maxM > 256 ? 4 : 2;
+        const int sR = b->maxM > 256 ? 4 : 2; /* (queries over 4096 rows would need more than 16 stripes: not split) */
         const int sW = dpx_tiled_stripes(b->maxM, sR);
         const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
         const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;

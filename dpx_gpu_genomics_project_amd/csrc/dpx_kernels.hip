@@ -2489,8 +2489,7 @@ hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int wa
     switch (R) {
         DPX_SPLIT_CASE(2)
         DPX_SPLIT_CASE(4)
-        DPX_SPLIT_CASE(8)
-    default: return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue; /* (8 rows per lane would spill under the 1024-thread launch bound) */
     }
 #undef DPX_SPLIT_CASE
 }
