@@ -1016,8 +1016,8 @@ template <int R>
 struct PkState {
     uint32_t Hl[R];   /* packed H[row][j-1] */
     uint32_t qc[R];   /* packed query characters (16-bit lanes) */
-    uint32_t rmax[R]; /* SW: packed per-row running maximum */
-    uint32_t rcol[R]; /* SW: packed column at which each half of rmax was first reached */
+    uint32_t rmax[R]; /* SW: per-row running maximum of pair A's key (H << 16 | 0xFFFF - column): max score, then smallest column */
+    uint32_t rcol[R]; /* SW: the same for pair B */
     uint32_t dtop;
 };
 
@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
     if (active) {
         uint32_t u = upin, d = st.dtop;
         const uint32_t onesP = 0x00010001u;
-        const uint32_t jP = ((uint32_t)j << 16) | (uint32_t)j;
+        const uint32_t negj = 0xFFFFu - (uint32_t)j;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t left = st.Hl[r];
@@ -1074,14 +1074,11 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
             u = as_u32(h);
             st.Hl[r] = u;
             if constexpr (LOCAL) {
-                /* first strict maximum of the row, per half, on the packed pipe: where h beats the running maximum the
-                 * difference is non-zero -> 0xFFFF mask -> the column is taken over (v_pk_max, v_pk_sub, v_pk_min,
-                 * v_pk_sub, v_bfi: 2.5 instructions per cell) */
-                const uint32_t nm = dpx::pk_max_u16_raw(st.rmax[r], u);
-                const uint32_t grew = dpx::pk_min_u16_raw(dpx::pk_sub_u16_raw(nm, st.rmax[r]), onesP);
-                const uint32_t mask = dpx::pk_sub_u16_raw(0u, grew);
-                st.rcol[r] = dpx::bfi_b32(mask, jP, st.rcol[r]);
-                st.rmax[r] = nm;
+                /* first strict maximum of the row, per pair: the int32 kernels' (score, column) key, one per half -- v_and_or_b32 /
+                 * v_lshl_or_b32 build it, v_max_u32 (v_max3_u32 across two unrolled steps) folds it: 3-4 ops per two cells where the
+                 * packed running-maximum + column select of round 1 took 5 */
+                st.rmax[r] = max(st.rmax[r], (u & 0xFFFF0000u) | negj);
+                st.rcol[r] = max(st.rcol[r], (u << 16) | negj);
             }
         }
         st.dtop = upin;
@@ -1173,6 +1170,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
             if (fast) {
                 int t = 0;
                 for (; t < 63; t++) DPX_PK_STEP(true, true, true)
+                for (; t + 1 < n;) { DPX_PK_STEP(false, true, true) t++; DPX_PK_STEP(false, true, true) t++; } /* two steps per trip: the keys of both fold with v_max3_u32 */
                 for (; t < n; t++) DPX_PK_STEP(false, true, true)
                 for (; t < W; t++) DPX_PK_STEP(true, true, true)
             } else {
@@ -1190,9 +1188,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         if constexpr (LOCAL) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const int hA = (int)(st.rmax[r] >> 16), hB = (int)(st.rmax[r] & 0xFFFFu);
-                if (r < nrows && hA > bestA) { bestA = hA; browA = row0 + 1 + r; bcolA = (int)(st.rcol[r] >> 16); }
-                if (r < nrows && hB > bestB) { bestB = hB; browB = row0 + 1 + r; bcolB = (int)(st.rcol[r] & 0xFFFFu); }
+                const int hA = (int)(st.rmax[r] >> 16), hB = (int)(st.rcol[r] >> 16);
+                if (r < nrows && hA > bestA) { bestA = hA; browA = row0 + 1 + r; bcolA = 0xFFFF - (int)(st.rmax[r] & 0xFFFFu); }
+                if (r < nrows && hB > bestB) { bestB = hB; browB = row0 + 1 + r; bcolB = 0xFFFF - (int)(st.rcol[r] & 0xFFFFu); }
             }
         }
     }
