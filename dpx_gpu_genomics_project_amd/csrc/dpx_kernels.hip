@@ -1744,7 +1744,7 @@ template <int C>
 struct BandStatePk {
     uint32_t prev[C], prev2[C]; /* anti-diagonals a-1 and a-2, {A, B} */
     uint32_t qch[C], rch[C];    /* query / reference characters in 16-bit lanes, {A, B} */
-    uint32_t rmax[C], rstep[C]; /* per slot: running maximum and the step it was first reached, {A, B} */
+    uint32_t rmax[C], rstep[C]; /* per slot: running maximum of the key (H << 16 | 0xFFFF - step) of pair A / of pair B */
     uint32_t inBand[2][C];      /* ~0 / 0: is slot s inside the band on a step of parity p (s <= B-1-p)? */
 };
 
@@ -1779,7 +1779,7 @@ __device__ __forceinline__ void band_step_pk(BandStatePk<C> &st, const int A, in
         for (int c = 0; c < C; c++) { left[c] = st.prev[c]; up[c] = (c > 0) ? st.prev[c - 1] : nb; }
     }
     const uint32_t onesP = 0x00010001u;
-    const uint32_t stepP = ((uint32_t)A << 16) | (uint32_t)A;
+    const uint32_t negA = 0xFFFFu - (uint32_t)A;
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const uint32_t differs = dpx::pk_min_u16_raw(st.qch[c] ^ st.rch[c], onesP);
@@ -1792,10 +1792,8 @@ __device__ __forceinline__ void band_step_pk(BandStatePk<C> &st, const int A, in
             const int s = lane * C + c;
             h = ((s >= smin) && (s <= smax)) ? h : 0u;
         }
-        const uint32_t nm = dpx::pk_max_u16_raw(st.rmax[c], h);
-        const uint32_t grew = dpx::pk_min_u16_raw(dpx::pk_sub_u16_raw(nm, st.rmax[c]), onesP);
-        st.rstep[c] = dpx::bfi_b32(dpx::pk_sub_u16_raw(0u, grew), stepP, st.rstep[c]);
-        st.rmax[c] = nm;
+        st.rmax[c] = max(st.rmax[c], (h & 0xFFFF0000u) | negA);  /* (score, earliest step) keys as in k_banded_fill, one per half */
+        st.rstep[c] = max(st.rstep[c], (h << 16) | negA);
         st.prev2[c] = st.prev[c];
         st.prev[c] = h;
         out[c] = h;
@@ -1893,9 +1891,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill_pk(const dpx_f
     for (int c = 0; c < C; c++) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const int hv = half ? (int)(st.rmax[c] & 0xFFFFu) : (int)(st.rmax[c] >> 16);
+            const uint32_t key = half ? st.rstep[c] : st.rmax[c];
+            const int hv = (int)(key >> 16);
             if (hv > 0) {
-                const int A = half ? (int)(st.rstep[c] & 0xFFFFu) : (int)(st.rstep[c] >> 16);
+                const int A = 0xFFFF - (int)(key & 0xFFFFu);
                 const int aa = A + 2;
                 const int pp = (aa + B - 1) & 1;
                 const int u = 2 * (lane * C + c) + pp;
