@@ -1215,10 +1215,16 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
     int32_t *hLen = reinterpret_cast<int32_t *>(hOff + np + 1);
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     if (!b->tbLinesValid) {
-        /* enough lanes in flight to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster) */
-        bool cachedWalk = b->numPairs >= 65536;
-        if (const char *env = getenv("DPX_TB_CACHED")) cachedWalk = atoi(env) != 0; /* tests force either walk */
-        HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, cachedWalk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
+        /* How to walk: one lane per pair -- through register-cached column vectors (walk 1) when there are enough lanes in flight
+         * to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster), cell by cell (walk
+         * 0) otherwise.  Walk 2 (one WAVE per pair with an LDS window, k_traceback_wave) is opt-in: it cuts the HBM round trips of
+         * a 1024 x 1024 path from 1100 to ~35, but 64 lanes repeating the walk cost more than that saves below ~1000 steps per
+         * path (5000 x 1024^2: 1.60 vs 1.83 ms LSW, 1.50 vs 1.53 LNW; 20k x 300^2: 1.30 vs 0.65 ms; 100k short reads: 2.1 vs
+         * 0.59 ms).  DPX_TB_WALK=0/1/2 forces one. */
+        int walk = b->numPairs >= 65536 ? 1 : 0;
+        if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
+        else if (const char *env = getenv("DPX_TB_CACHED")) walk = atoi(env) != 0 ? 1 : 0; /* (round-1 knob, tests) */
+        HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
         b->tbLinesValid = true;
     }
     HIP_TRY(dpx_launch_output(b->dPairs, b->dScore, b->dTbLen, b->dTbOff, b->dTb, (int)np, (unsigned long long)firstNumber,

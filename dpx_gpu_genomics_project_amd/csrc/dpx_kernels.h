@@ -50,9 +50,10 @@ hipError_t dpx_launch_banded_packed(const dpx_fill_args &a, int C, size_t ldsByt
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,
                              int gapExtend, int band, int16_t *out, hipStream_t stream);
-/* cachedWalk: LSW / LNW walk through register-resident 8-row column vectors (pays off when the batch is large enough to
- * be bound by sector requests rather than by load latency) */
-hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, bool cachedWalk,
+/* walk: 0 = one lane per pair, three parallel 2-byte loads per step; 1 = one lane per pair through register-resident 8-row
+ * column vectors (LSW / LNW, pays off when the batch is bound by sector requests rather than by load latency); 2 = one WAVE
+ * per pair with an LDS window of 32 rows x 64 columns (LSW / LNW on layouts with 8-row vectors; other pairs fall back to 0) */
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, int walk,
                                 const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream);
 size_t dpx_out_scan_tiles(size_t numPairs);
 hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff, const char *tb,

@@ -2059,10 +2059,9 @@ struct TileWalker {
     }
 };
 
-__global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R, int planes, int cachedWalk, const int32_t *endRow,
-                            const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= numPairs) return;
+/* one lane walks one pair */
+__device__ void tb_walk_lane(const dpx_fill_args &a, const int p, int algo, int R, int planes, int cachedWalk, const int32_t *endRow,
+                             const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
@@ -2181,6 +2180,134 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
         }
     }
     tbLen[p] = cap - pos;
+}
+
+__global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R, int planes, int cachedWalk, const int32_t *endRow,
+                            const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numPairs) return;
+    tb_walk_lane(a, p, algo, R, planes, cachedWalk, endRow, endCol, tbOff, tb, tbLen);
+}
+
+/* -----------------------------------------------------------------------------------------------------
+ * Wave-cooperative traceback (LSW / LNW on layouts whose 8-row groups are 16 contiguous bytes: rows per lane >= 8).
+ * The lane-per-pair walk above pays one dependent HBM round trip per path step (1100 of them on a 1024 x 1024 pair).  Here
+ * one WAVE owns a pair: its 64 lanes fetch a window of the matrix around the walker in one go -- 4 row groups (32 rows) x 64
+ * columns, four 16-byte loads per lane, plus the query / reference characters of those rows / columns -- into LDS, and the
+ * walk (computed by all lanes alike, emitted by lane 0) then runs out of LDS until it leaves the window through its top or its
+ * left edge: one HBM round trip per ~32 steps of a diagonal path instead of one per step.
+ * ----------------------------------------------------------------------------------------------------- */
+constexpr int kWinGroups = 4, kWinCols = 64;
+
+__global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int algo, int R, int planes, const int32_t *endRow,
+                                                       const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
+    __shared__ u32x4 win[kWinGroups][kWinCols];
+    __shared__ unsigned char wq[8 * kWinGroups + 8], wr[kWinCols + 8];
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (p >= numPairs) return;
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = pr.n, m = pr.m;
+    const int Rr = pr.rows ? (int)pr.rows : R;
+    const bool eligible = (algo == DPX_K_LSW || algo == DPX_K_LNW) && Rr >= 8 && (pr.lanes == 64 || pr.lanes == 16) && m > 0 && n > 0;
+    if (!eligible) { /* other layouts / algorithms: the one-lane walk (wave-uniform branch) */
+        if (lane == 0) tb_walk_lane(a, p, algo, R, planes, 0, endRow, endCol, tbOff, tb, tbLen);
+        return;
+    }
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    const int cap = (m + n + 1 + 3) & ~3;
+    char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
+    int pos = cap;
+    uint32_t accR = 0, accX = 0, accQ = 0;
+    const int match = a.match, mismatch = a.mismatch, g = a.gapOpen;
+    const int border = algo == DPX_K_LNW ? g : 0; /* H on row 0 / column 0 is border * (i + j) */
+    TileWalker tw{a.mat, pr.matOff, pr.chunkStride, pr.lanes, n, dpx_log2(Rr), border}; /* (only its column() is used) */
+#define EMITW(rc_, xc_, qc_)                                                                     \
+    {                                                                                            \
+        --pos;                                                                                   \
+        accR = (accR << 8) | (uint32_t)(unsigned char)(rc_);                                     \
+        accX = (accX << 8) | (uint32_t)(unsigned char)(xc_);                                     \
+        accQ = (accQ << 8) | (uint32_t)(unsigned char)(qc_);                                     \
+        if ((pos & 3) == 0 && lane == 0) {                                                       \
+            *reinterpret_cast<uint32_t *>(lr + pos) = accR;                                      \
+            *reinterpret_cast<uint32_t *>(lx + pos) = accX;                                      \
+            *reinterpret_cast<uint32_t *>(lq + pos) = accQ;                                      \
+        }                                                                                        \
+    }
+    int i = endRow[p], j = endCol[p];
+    int gBase = 0, cLo = 1; /* window: row groups gBase .. gBase+3 (rows 8*gBase+1 ..), columns cLo .. cLo+63 */
+    auto load_window = [&](const int ii, const int jj) { /* anchored so that (ii, jj) is its bottom-right corner region */
+        gBase = ((ii - 1) >> 3) - (kWinGroups - 1);
+        cLo = jj - (kWinCols - 1);
+        const int jc = cLo + lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the previous window's reads are done before it is overwritten */
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int gi = 0; gi < kWinGroups; gi++) {
+            const int grp = gBase + gi;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v = tw.column(grp * 8, jc);
+            win[gi][lane] = v;
+        }
+        if (lane < 8 * kWinGroups) { const int qi = gBase * 8 + lane; wq[lane] = (qi >= 0 && qi < m) ? qry[qi] : 0; }
+        wr[lane] = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto need_window = [&]() -> bool { /* rows i-1, i and columns j-1, j (those >= 1) must lie inside the window */
+        const int rTop = min(i, max(i - 1, 1)), cLeft = min(j, max(j - 1, 1));
+        return (i >= 1 && ((rTop - 1) >> 3) < gBase) || (j >= 1 && cLeft < cLo) || (i >= 1 && ((i - 1) >> 3) > gBase + kWinGroups - 1) ||
+               (j >= 1 && j > cLo + kWinCols - 1);
+    };
+    auto H = [&](const int ii, const int jj) -> int {
+        if (ii == 0 || jj == 0) return border * (ii + jj);
+        const int16_t *w = reinterpret_cast<const int16_t *>(&win[((ii - 1) >> 3) - gBase][jj - cLo]);
+        return (int)w[(ii - 1) & 7];
+    };
+    auto qc_of = [&](const int ii) -> int { return wq[(ii - 1) - gBase * 8]; };  /* query character of row ii */
+    auto rc_of = [&](const int jj) -> int { return wr[jj - cLo]; };              /* reference character of column jj */
+    gBase = 1 << 28; /* no window yet */
+    if (algo == DPX_K_LSW) {
+        int h = 0;
+        if (i > 0 && j > 0) { load_window(i, j); h = H(i, j); }
+        while (h > 0) {
+            if (need_window()) load_window(i, j);
+            const int up = H(i - 1, j), left = H(i, j - 1);
+            if (up + g == h) { EMITW('_', ' ', qc_of(i)); i--; h = up; }
+            else if (left + g == h) { EMITW(rc_of(j), ' ', '_'); j--; h = left; }
+            else {
+                const int dg = H(i - 1, j - 1), qc = qc_of(i), rc = rc_of(j);
+                EMITW(rc, qc == rc ? '*' : '|', qc);
+                i--; j--; h = dg;
+            }
+        }
+    } else {
+        while (i != 0 || j != 0) {
+            if (need_window()) load_window(max(i, 1), max(j, 1));
+            if (i == 0) { EMITW(rc_of(j), ' ', '_'); j--; continue; }  /* row-0 border: QUERY_INSERTION */
+            if (j == 0) { EMITW('_', ' ', qc_of(i)); i--; continue; }  /* column-0 border: QUERY_DELETION */
+            const int qc = qc_of(i), rc = rc_of(j);
+            const bool eq = qc == rc;
+            const int mm = H(i - 1, j - 1) + (eq ? match : mismatch);
+            const int del = H(i - 1, j) + g, ins = H(i, j - 1) + g;
+            const int vmax = max(del, mm);
+            if (ins >= vmax) { EMITW(rc, ' ', '_'); j--; }
+            else if (del >= mm) { EMITW('_', ' ', qc); i--; }
+            else { EMITW(rc, eq ? '*' : '|', qc); i--; j--; }
+        }
+    }
+#undef EMITW
+    if (lane == 0) {
+        if (pos & 3) {
+            const int left = 4 - (pos & 3);
+            for (int t = 0; t < left; t++) {
+                lr[pos + t] = (char)(accR >> (8 * t)); lx[pos + t] = (char)(accX >> (8 * t)); lq[pos + t] = (char)(accQ >> (8 * t));
+            }
+        }
+        tbLen[p] = cap - pos;
+    }
 }
 
 /* =====================================================================================================
@@ -2555,9 +2682,15 @@ hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int alg
     return hipGetLastError();
 }
 
-hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, bool cachedWalk,
+hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, int R, int planes, int walk,
                                 const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream) {
     if (numPairs <= 0) return hipSuccess;
+    const bool cachedWalk = walk == 1;
+    if (walk == 2) { /* one wave per pair with an LDS window (k_traceback_wave) */
+        hipLaunchKernelGGL(k_traceback_wave, dim3((unsigned)numPairs), dim3(64), 0, stream, a, numPairs, algo, R, planes, a.endRow, a.endCol, tbOff, tb,
+                           tbLen);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,
                        cachedWalk ? 1 : 0, a.endRow, a.endCol, tbOff, tb, tbLen);
     return hipGetLastError();

@@ -72,18 +72,21 @@ def test_banded_traceback_vs_oracle(gpu):
             assert b.traceback(p) == want, p
 
 
-@pytest.mark.parametrize("cached", ["0", "1"])
+@pytest.mark.parametrize("cached", ["0", "1", "2"])
 @pytest.mark.parametrize("algo", ["LSW", "LNW"])
-def test_both_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
-    """Large batches walk through register-cached 8-row column vectors, small ones load cell by cell (DPX_TB_CACHED forces
-    either): 8- and 16-row tiles, several stripes, lane-group and stripe crossings, the quad layout, borders reached from
-    both sides, empty sequences -- every printed line against the oracle."""
-    monkeypatch.setenv("DPX_TB_CACHED", cached)
+def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
+    """Three ways to walk (DPX_TB_WALK forces one): 0 = one lane per pair, cell by cell; 1 = one lane per pair through register-
+    cached 8-row column vectors; 2 = one wave per pair with an LDS window of 32 rows x 64 columns (the default where the layout
+    has 8-row vectors).  8- and 16-row tiles, several stripes, lane-group, stripe and window crossings, the lane-packed tile
+    layout, the split layout (falls back to walk 0), borders reached from both sides, empty sequences -- every printed line
+    against the oracle."""
+    monkeypatch.setenv("DPX_TB_WALK", cached)
     w = (3, -1, -2, -1)
     batches = [make_batch(5, 300, 280, seed=51, first_index=96),          # R = 8, one stripe
                make_batch(4, 700, 150, seed=52, first_index=96),          # R = 16, rows 512.. in the second sub-tile
                make_batch(3, 40, 600, seed=53), make_batch(3, 600, 40, seed=54),
-               from_strings([("", "0123"), ("0123", ""), ("0123", "0123"), ("3", "0123012301230123"), ("0123012301230123", "3")])]
+               from_strings([("", "0123"), ("0123", ""), ("0123", "0123"), ("3", "0123012301230123"), ("0123012301230123", "3"),
+                             ("0" * 300, "1" * 200 + "0" * 90), ("01" * 150, "10" * 40)])]   # long gaps: the walk leaves windows sideways
     for r, quad in (("8", "0"), ("8", "1"), ("16", "0")):
         monkeypatch.setenv("DPX_R", r)
         monkeypatch.setenv("DPX_QUAD", quad)
