@@ -258,7 +258,7 @@ struct dpx_batch {
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
     int splitWaves = 0;
     size_t splitLds = 0;
-    bool quad = false;     /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
+    bool lanePacked = false; /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
                               descriptors in dCouples, launch arguments in pkArgs */
     int32_t *dCouples = nullptr;
     dpx_fill_args pkArgs{};
@@ -680,17 +680,22 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
      * query fits one stripe (the packed kernel has no rolling schedule); DPX_PACKED=0/1 overrides. */
     /* Lane-packed path (short reads, the reference's own dataset shape): queries of <= 512 rows in a batch large enough to
      * fill the chip with a fraction of the waves run several pairs per wave, ceil(m/8) lanes each (k_linear_lanes /
-     * k_affine_lanes, 8 x 8 tile layout); DPX_QUAD=0/1 overrides. */
+     * k_affine_lanes, tile layout); DPX_LANES=0/1 overrides. */
     const bool linearAlgo = kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW;
-    const bool quadAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
+    const bool lanesAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
     /* (the staged references of a wave's pairs share its LDS: keep the path to references that leave the request small) */
     const int kLanesR = lanes_rows(b->maxM, kernelAlgo);
-    const bool quadShape = quadAlgo && b->maxM <= 64 * kLanesR && b->maxM > 0 && b->maxN <= 4096;
-    bool useQuad = quadShape && b->maxM <= 256 && numPairs >= 8192; /* measured crossover on short reads (tools/quad_threshold.py) */
-    if (const char *env = getenv("DPX_QUAD")) useQuad = atoi(env) != 0 && quadShape;
+    const bool lanesShape = lanesAlgo && b->maxM <= 64 * kLanesR && b->maxM > 0 && b->maxN <= 4096;
+    /* measured (tools/lanes_threshold.py): short reads x2048 56 vs 66 us, x4096 56 vs 114, x16384 121 vs 222 (below 2048 pairs the
+     * split / one-wave-per-pair kernels win); 20000 x 250x300 (32 lanes per pair, two per wave) 608 vs 645 us, but 300x300 (38 lanes, one
+     * per wave) 1074 vs 818 and 180x200 (23 lanes, two per wave) 395 vs 363: the path pays when the packing fills the lanes */
+    bool useLanes = lanesShape && b->maxM <= 256 && numPairs >= 2048;
+    bool lanesForced = false;
+    if (const char *env = getenv("DPX_LANES")) { useLanes = atoi(env) != 0 && lanesShape; lanesForced = true; }
+    else if (const char *env = getenv("DPX_QUAD")) { useLanes = atoi(env) != 0 && lanesShape; lanesForced = true; } /* (round-1 name of the knob) */
     std::vector<dpx_wave_desc> waves;
     size_t lanesRefArea = 0, lanesPairs = 0;
-    if (useQuad) {
+    if (useLanes) {
         b->R = kLanesR; /* empty pairs, if any, run on the one-pair-per-wave kernel at this tile height (they have no cells) */
         for (size_t i = 0; i < numPairs; i++) {
             dpx_pair_dev &pd = b->pairs[i];
@@ -711,13 +716,25 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             pass(tmp, couples, b->maxN, [&](int32_t c) { return b->pairs[c].n; });
         }
         lanesPairs = couples.size();
-        b->quad = !couples.empty();
-        if (b->quad) lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
-        else { b->R = R; singles.clear(); }
+        b->lanePacked = !couples.empty();
+        if (b->lanePacked) {
+            lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
+            size_t lanesUsed = 0;
+            for (const dpx_wave_desc &wd : waves) for (int k = 0; k < DPX_WAVE_SLOTS; k++) lanesUsed += wd.num[k];
+            if (!lanesForced && lanesUsed * 100 < waves.size() * 64 * 85) b->lanePacked = false; /* under 85 % of the lanes own rows: not worth it */
+        }
+        if (!b->lanePacked) { /* back to the other kernels */
+            b->R = R;
+            singles.clear();
+            couples.clear();
+            waves.clear();
+            lanesPairs = 0;
+            for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 64; b->pairs[i].rows = 0; }
+        }
     }
-    bool usePacked = !b->quad && b->store && ((linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1) || banded) &&
+    bool usePacked = !b->lanePacked && b->store && ((linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1) || banded) &&
                      numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
-    if (b->quad) usePacked = false;
+    if (b->lanePacked) usePacked = false;
     else
     if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (linearAlgo || banded);
     /* 16-bit wrapping arithmetic: only when weights and every intermediate provably fit (also under DPX_PACKED=1) */
@@ -768,7 +785,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         const int sW = dpx_tiled_stripes(b->maxM, sR);
         const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
         const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;
-        const bool shape = linearAlgo && b->store && !b->quad && !b->packed && !anyEmpty && numPairs > 0 && sW >= 2 && sW <= 16 && lds <= 160u * 1024u;
+        const bool shape = linearAlgo && b->store && !b->lanePacked && !b->packed && !anyEmpty && numPairs > 0 && sW >= 2 && sW <= 16 && lds <= 160u * 1024u;
         /* measured (tools/ab_fill.py, DPX_SPLIT=0/1): 100 x 512^2 +25 %, 500 x 1024^2 +39 %, 1000 x 512^2 +1 %, 1000 x 1024^2 (4000 waves)
          * -13 %: worth it while the split batch stays within about two waves per SIMD */
         bool useSplit = shape && numPairs * (size_t)sW <= 2304;
@@ -821,7 +838,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     trace.mark("create: arena");
     if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
     trace.mark("create: H2D sequences");
-    if (b->quad) {
+    if (b->lanePacked) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, waves.data(), waves.size() * sizeof(dpx_wave_desc), hipMemcpyHostToDevice));
     } else if (b->packed) {
@@ -838,13 +855,13 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         b->dOrder = arenaOrder;
         CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    const size_t numSingles = (b->packed || b->quad) ? singles.size() : numPairs;
+    const size_t numSingles = (b->packed || b->lanePacked) ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
     /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
     int numStreams = 0;
     {
-        bool want = b->store && !b->packed && !b->quad && !b->split && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
+        bool want = b->store && !b->packed && !b->lanePacked && !b->split && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
                     b->pairs[0].m > 0 && b->pairs[0].n >= 128;
         /* opt-in: bit-exact and 3 % fewer bytes written, but not faster than one launch-scheduled wave per pair -- the
          * fill is bound by store instructions per CU-cycle either way (profiles/README.md) */
@@ -912,7 +929,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
                 off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
             }
         } else if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave = two adjacent slots */
-        else if (b->quad) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
+        else if (b->lanePacked) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
             const uint32_t stepElems = dpx_wtile_step_elems(b->R / 8, b->planes);
             for (const dpx_wave_desc &wd : waves) {
                 uint64_t steps = 0;
@@ -927,7 +944,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             }
         }
         if (b->streamed) {
-        } else if (b->packed || b->quad || !singles.empty()) {
+        } else if (b->packed || b->lanePacked || !singles.empty()) {
             place(singles, (size_t)group, chunkElems);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
@@ -1011,9 +1028,10 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         k.ldsPerWave = (uint32_t)(pkEdge + pkRef);
         k.ldsRefOff = (uint32_t)pkEdge;
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
+        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if (b->quad) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + the staged references of its pairs */
+    if (b->lanePacked) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + the staged references of its pairs */
         dpx_fill_args &k = b->pkArgs;
         k = a;
         k.order = nullptr;
@@ -1024,7 +1042,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if ((b->packed || b->quad) && numSingles > 0) {
+    if ((b->packed || b->lanePacked) && numSingles > 0) {
         /* more than one kernel per fill: a side stream + fork/join events (failure here only costs the overlap) */
         if (stream_take(&b->sideStream) != hipSuccess) { b->sideStream = nullptr; (void)hipGetLastError(); }
         if (b->sideStream && (hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming) != hipSuccess ||
@@ -1032,8 +1050,8 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     }
     b->nSingles = numSingles;
     b->nCouples = b->packed ? numCouples : 0;
-    b->nLanePairs = b->quad ? lanesPairs : 0;
-    b->nWaves = b->quad ? waves.size() : 0;
+    b->nLanePairs = b->lanePacked ? lanesPairs : 0;
+    b->nWaves = b->lanePacked ? waves.size() : 0;
     *out = b;
     return DPX_OK;
 }
@@ -1047,7 +1065,7 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     const bool hasMain = b->args.numPairs > 0;
     int kernels = 0;
     if (b->packed) kernels++;
-    if (b->quad) kernels++;
+    if (b->lanePacked) kernels++;
     if (hasMain) kernels++;
     hipStream_t side = s;
     bool forked = false;
@@ -1060,7 +1078,7 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     }
     hipError_t e = hipSuccess;
     /* secondary kernel first (it is the short one; the main kernel then fills the chip around it) */
-    if (b->quad) {
+    if (b->lanePacked) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side); /* empty pairs */
         if (e == hipSuccess) e = dpx_launch_fill_lanes(b->pkArgs, b->kernelAlgo, b->R, b->store, b->pkLdsBytes, s);
     } else if (b->packed) {
@@ -1349,8 +1367,8 @@ int dpx_batch_traceback(dpx_batch *b, size_t pair, char *refLine, char *relLine,
 int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
-    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->quad ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->quad ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+    const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
+                         : b->packed ? "k_linear_fill_pk" : b->lanePacked ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d",
              names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,

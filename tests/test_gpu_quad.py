@@ -110,3 +110,19 @@ def test_quad_is_the_default_for_large_short_read_batches(gpu):
             assert sc[p] == o.score
             if p % (97 * 8) == 0:
                 assert np.array_equal(b.matrix(p).astype(np.int32), o.H)
+
+
+def test_lanes_are_chosen_where_the_packing_fills_the_wave(gpu):
+    """>= 2048 pairs of <= 256 rows take the lane-packed kernels when >= 85 % of the lanes end up owning rows."""
+    for sb, want in ((make_ragged_batch(2100, 80, 130, 100, 160, seed=40), True),    # 10-17 lanes per pair: ~94 % of the lanes
+                     (make_batch(2100, 250, 120, seed=41), True),                     # 32 lanes per pair, two per wave
+                     (make_batch(2100, 180, 120, seed=42), False),                    # 23 lanes per pair: two per wave, 72 %
+                     (make_ragged_batch(2000, 80, 130, 100, 160, seed=43), False)):   # too few pairs
+        with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, 3, -1, -2) as b:
+            d = b.describe()
+            assert (d["kernel"] == "k_linear_lanes") == want, d
+            b.fill()
+            sc, _, _ = b.results()
+            for p in range(0, sb.num_pairs, 211):
+                o = O.lnw(sb.ref(p), sb.qry(p), 3, -1, -2)
+                assert sc[p] == o.score and np.array_equal(b.matrix(p).astype(np.int32), o.H)
