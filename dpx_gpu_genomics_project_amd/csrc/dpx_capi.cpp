@@ -786,9 +786,12 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
         const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;
         const bool shape = linearAlgo && b->store && !b->lanePacked && !b->packed && !anyEmpty && numPairs > 0 && sW >= 2 && sW <= 16 && lds <= 160u * 1024u;
-        /* measured (tools/ab_fill.py, DPX_SPLIT=0/1): 100 x 512^2 +25 %, 500 x 1024^2 +39 %, 1000 x 512^2 +1 %, 1000 x 1024^2 (4000 waves)
-         * -13 %: worth it while the split batch stays within about two waves per SIMD */
-        bool useSplit = shape && numPairs * (size_t)sW <= 2304;
+        /* measured (bench.py --pairs N, DPX_SPLIT=0/1, HIP events around every fill; GCUPS split vs one wave per pair):
+         *   1024 x 1024 (4 stripes of 4 rows per lane against ONE 16-rows-per-lane wave): 600 pairs 1864 vs 1768, 1200: 2229 vs 1765,
+         *   2500: 2483 vs 2315, 3500: 2592 vs 2393, 4096: 2603 vs 2671 (and the packed kernel takes over);
+         *   512 x 512 (2 stripes against one 8-rows-per-lane wave): 500 pairs 1021 vs 1003, 1000: 2084 vs 2003, 1500: 1841 vs 1935.
+         * So: any shape up to ~1100 pairs, shapes of four or more stripes up to the packed kernel's threshold. */
+        bool useSplit = shape && (numPairs <= 1100 || (sW >= 4 && numPairs < 4096));
         if (const char *env = getenv("DPX_SPLIT")) useSplit = atoi(env) != 0 && shape;
         if (useSplit) {
             b->split = true;
