@@ -194,7 +194,9 @@ def main():
         sb = make_ragged_batch(npairs, 80, 130, 100, 160, seed=seed + 1000 * rank)
     else:
         sb = dpx.make_batch(npairs, m, n, seed=seed + 1000 * rank, first_index=rank * npairs)
-    batch = dpx.Batch(algo, sb.sequences, sb.pairs, match, mismatch, gap_open, gap_extend, band=BAND if algo_name == "BSW" else 0)
+    # the resident batch is filled steps + warmup times: let the engine shop for a well-placed matrix pool
+    batch = dpx.Batch(algo, sb.sequences, sb.pairs, match, mismatch, gap_open, gap_extend, band=BAND if algo_name == "BSW" else 0,
+                      flags=dpx.TUNE_PLACEMENT)
     info = batch.info()
     # a dedicated (non-null) torch stream is made current: the fill kernel, the HIP events that time it and the
     # RCCL gather are all ordered on it

@@ -13,7 +13,7 @@ import numpy as np
 
 ALGO_LNW, ALGO_LSW, ALGO_ANW, ALGO_BSW = 0, 1, 2, 3
 ALGO_NAMES = {ALGO_LNW: "LNW", ALGO_LSW: "LSW", ALGO_ANW: "ANW", ALGO_BSW: "BSW"}
-KEEP_MATRICES, SCORE_ONLY, TIME_FILLS = 0x0, 0x1, 0x2
+KEEP_MATRICES, SCORE_ONLY, TIME_FILLS, TUNE_PLACEMENT = 0x0, 0x1, 0x2, 0x4
 MAT_H, MAT_I, MAT_D = 0, 1, 2
 
 # every symbol include/dpx_align.h declares (tests check the .so exports all of them)

@@ -499,11 +499,10 @@ static uint64_t band_cells(long long m, long long n, long long B) {
 /* Where a big allocation lands in HBM matters: the same 22 GB matrix pool is written at 6.3 TB/s or at 6.05 TB/s by
  * hipMemset depending on the allocation (measured, tools/pool_state.py: two modes, stable for the life of the allocation,
  * and the fill kernels follow it one to one -- the "fast / slow box state" of round 1).  A fresh pool of a GiB or more
- * is therefore probed: up to four candidate allocations are timed with a memset each, the fastest is kept and parked for
- * every later batch, the others are freed.  Costs ~10 ms per candidate, once per process and pool size; DPX_POOL_PROBE=0
- * turns it off. */
+ * of a batch created with DPX_TUNE_PLACEMENT is therefore probed: up to four candidate allocations are timed with a memset
+ * each, the fastest is kept and parked for every later batch, the others are freed.  Costs the allocations (0.1 - 2 s for tens
+ * of GB) + ~10 ms of memsets per candidate, once per process and pool size: for batches that are filled many times. */
 static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace) {
-    if (const char *env = getenv("DPX_POOL_PROBE")) if (atoi(env) == 0) return first;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return first; }
     auto probe = [&](void *p) -> float {
@@ -970,7 +969,11 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         void *pool = nullptr;
         bool fresh = false;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes, &fresh));
-        if (fresh && b->matPoolBytes >= ((size_t)1 << 30)) pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace);
+        /* placement tuning costs up to three more allocations of the pool's size (0.1 - 2 s for tens of GB): only for callers that
+         * say the batch is going to be filled many times (DPX_TUNE_PLACEMENT; DPX_POOL_PROBE=1 / 0 forces it on / off) */
+        bool tune = (flags & DPX_TUNE_PLACEMENT) != 0;
+        if (const char *env = getenv("DPX_POOL_PROBE")) tune = atoi(env) != 0;
+        if (tune && fresh && b->matPoolBytes >= ((size_t)1 << 30)) pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace);
         b->dMat = (int16_t *)pool;
 
     }

@@ -25,7 +25,7 @@ assert lib.dpx_init(0) == 0
 prm = Params({"LNW": 0, "LSW": 1, "ANW": 2, "BSW": 3}[algo_name], match, mismatch, go, ge, BAND if algo_name == "BSW" else 0)
 h = vp()
 seq = np.ascontiguousarray(sb.sequences); prs = np.ascontiguousarray(sb.pairs, dtype=PAIR_DTYPE)
-assert lib.dpx_batch_create(C.byref(prm), seq.ctypes.data, seq.size, prs.ctypes.data, 0, npairs, 0, C.byref(h)) == 0
+assert lib.dpx_batch_create(C.byref(prm), seq.ctypes.data, seq.size, prs.ctypes.data, 0, npairs, 4, C.byref(h)) == 0  # DPX_TUNE_PLACEMENT (ignored by older builds)
 us = C.c_double()
 lib.dpx_batch_fill_timed(h, 20, C.byref(us))
 best = []

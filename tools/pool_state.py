@@ -7,6 +7,7 @@ import os
 import sys
 
 os.environ["DPX_TRACE"] = "1"
+os.environ.setdefault("DPX_POOL_PROBE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpx_gpu_genomics_project_amd as dpx  # noqa: E402
 
