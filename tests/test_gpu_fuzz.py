@@ -32,8 +32,8 @@ def random_batch(rng, count, max_len, alphabet):
 
 import os
 
-# DPX_FUZZ_SEEDS=N widens the sweep (default 3 seeds per algorithm; the committed suite stays fast)
-SEEDS = list(range(1, 1 + int(os.environ.get("DPX_FUZZ_SEEDS", "3"))))
+# DPX_FUZZ_SEEDS=N widens the sweep (default 6 seeds per algorithm; the committed suite stays fast)
+SEEDS = list(range(1, 1 + int(os.environ.get("DPX_FUZZ_SEEDS", "6"))))
 QUAD_SEEDS = [100 + s for s in SEEDS[: max(2, len(SEEDS) // 2)]]
 
 WEIGHTS = [(3, -1, -2, -1), (1, -1, -1, -1), (2, -3, 0, -1), (0, 0, 0, 0), (5, 2, -4, -2), (1, -2, 1, -3), (7, -5, -9, 1)]
