@@ -49,7 +49,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #ifndef DPX_EXP_NORAMPSTORE
 #define DPX_EXP_NORAMPSTORE 0
 #endif
-/* ablation builds of the quad kernels (tools/ab_quad.sh): 1 = no global stores, 2 = stores without the LDS round trip */
+/* ablation builds of the lane-packed kernels (tools/ab_quad.sh): 1 = no global stores, 2 = stores without the LDS round trip */
 #ifndef DPX_EXP_QUAD
 #define DPX_EXP_QUAD 0
 #endif
@@ -1992,7 +1992,7 @@ struct CharWin {
     }
 };
 
-/* The H plane seen through two registers-resident column vectors.  In the tiled and quad layouts with R >= 8 the 8 rows
+/* The H plane seen through two registers-resident column vectors.  In the wavefront-tiled and the tile layout with R >= 8 the 8 rows
  * (i0 & ~7 .. +7) of one column are 16 contiguous, 16-byte aligned bytes: `cur` holds them for column j, `prev` for
  * column j-1.  A path step then needs at most ONE new 16-byte load (the next column on a left / diagonal move; two when
  * the walk climbs into the 8-row group above) instead of three 2-byte loads that each miss every cache. */
@@ -2088,7 +2088,7 @@ __device__ void tb_walk_lane(const dpx_fill_args &a, const int p, int algo, int 
     }
     int i = endRow[p], j = endCol[p];
     CharWin qw{qry}, rw{ref};
-    /* register-cached columns: LSW / LNW on the tiled or quad layout with 8-row sub-tiles (rows per lane >= 8), for
+    /* register-cached columns: LSW / LNW on the wavefront-tiled or the tile layout with 8-row sub-tiles (rows per lane >= 8), for
      * batches with enough lanes in flight that the walk is bound by sector requests (measured: 100k short pairs -25 %);
      * smaller batches are bound by the latency of one dependent load per step instead, and there the plain
      * three-loads-in-parallel step is the shorter chain (5000 x 1024^2: cached +40 %, 20k x 300^2: +10 %).  The host decides. */

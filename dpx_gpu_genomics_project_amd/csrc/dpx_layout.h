@@ -49,7 +49,7 @@ typedef struct dpx_pair_dev {
     uint32_t chunkStride; /* int16 elements between consecutive chunks (steps) of this pair */
     uint16_t lanes;       /* layout tag -- 64: wavefront-tiled (one wave per pair); 16: 8x8 tiles (lane-packed kernels, several pairs per
                              wave); 32: split (k_linear_split, one wave per stripe) */
-    uint16_t rows;        /* rows per lane of the kernel that fills this pair (quad batches mix 8 and 16); 0 = the batch's */
+    uint16_t rows;        /* rows per lane of the kernel that fills this pair (lane-packed and split batches set it); 0 = the batch's */
 } dpx_pair_dev;
 
 /* Lane-packed kernels (k_linear_lanes / k_affine_lanes): what one wave aligns.  Up to DPX_WAVE_SLOTS pairs share the 64
