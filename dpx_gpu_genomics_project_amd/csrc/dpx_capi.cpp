@@ -499,7 +499,7 @@ static uint64_t band_cells(long long m, long long n, long long B) {
 /* Where a big allocation lands in HBM matters: the same 22 GB matrix pool is written at 6.3 TB/s or at 6.05 TB/s by
  * hipMemset depending on the allocation (measured, tools/pool_state.py: two modes, stable for the life of the allocation,
  * and the fill kernels follow it one to one -- the "fast / slow box state" of round 1).  A fresh pool of a GiB or more
- * of a batch created with DPX_TUNE_PLACEMENT is therefore probed: up to four candidate allocations are timed with a memset
+ * of a batch created with DPX_TUNE_PLACEMENT is therefore probed: up to six candidate allocations are timed with a memset
  * each, the fastest is kept and parked for every later batch, the others are freed.  Costs the allocations (0.1 - 2 s for tens
  * of GB) + ~10 ms of memsets per candidate, once per process and pool size: for batches that are filled many times. */
 static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace) {
@@ -515,10 +515,11 @@ static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTra
         }
         return best;
     };
-    void *cand[4] = {first, nullptr, nullptr, nullptr};
-    float t[4] = {probe(first), 0, 0, 0};
+    constexpr int kMaxCand = 6; /* both modes come up about equally often: six candidates miss the fast one in ~2 % of the runs */
+    void *cand[kMaxCand] = {first};
+    float t[kMaxCand] = {probe(first)};
     int n = 1, bestIdx = 0;
-    for (; n < 4; n++) {
+    for (; n < kMaxCand; n++) {
         float lo = t[0], hi = t[0];
         for (int k = 1; k < n; k++) { lo = std::min(lo, t[k]); hi = std::max(hi, t[k]); }
         if (n >= 2 && hi > lo * 1.02f) break; /* both modes seen: the fast one is among the candidates */
@@ -969,7 +970,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         void *pool = nullptr;
         bool fresh = false;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes, &fresh));
-        /* placement tuning costs up to three more allocations of the pool's size (0.1 - 2 s for tens of GB): only for callers that
+        /* placement tuning costs up to five more allocations of the pool's size (0.1 - 2 s for tens of GB): only for callers that
          * say the batch is going to be filled many times (DPX_TUNE_PLACEMENT; DPX_POOL_PROBE=1 / 0 forces it on / off) */
         bool tune = (flags & DPX_TUNE_PLACEMENT) != 0;
         if (const char *env = getenv("DPX_POOL_PROBE")) tune = atoi(env) != 0;

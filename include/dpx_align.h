@@ -69,7 +69,7 @@ typedef struct dpx_params {
 #define DPX_KEEP_MATRICES 0x0u /* default: write the int16 score matrices (H; H,I,D for ANW) to HBM */
 #define DPX_SCORE_ONLY    0x1u /* no matrix writeback (not HBM-bound; never used for the roofline figure) */
 #define DPX_TIME_FILLS    0x2u /* bracket every dpx_batch_fill() with HIP events: dpx_batch_last_fill_usec() */
-#define DPX_TUNE_PLACEMENT 0x4u /* the batch will be filled many times: spend up to three extra allocations of the matrix pool (>= 1 GiB)
+#define DPX_TUNE_PLACEMENT 0x4u /* the batch will be filled many times: spend up to five extra allocations of the matrix pool (>= 1 GiB)
                                    to pick a well-placed one -- where a big allocation lands in HBM is worth +-4 % of write bandwidth */
 
 /* matrix selectors for dpx_batch_matrix */
