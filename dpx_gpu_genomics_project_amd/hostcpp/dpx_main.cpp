@@ -152,6 +152,12 @@ int main(int argc, char *argv[]) {
         if (print && (rc = dpx_batch_output_begin(next.b, shardFirst + first)) != DPX_OK) die("TRACEBACK LAUNCH FAILED", rc);
         if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
         filling = next;
+        // Two batches in flight need two matrix pools.  Allocating tens of GB costs hundreds of ms (more than the overlap of one
+        // batch's traceback with the next batch's fill can ever win back), so batches with big pools run one after the other and
+        // share ONE parked pool; the printer thread still overlaps.
+        uint64_t matrixBytes = 0;
+        dpx_batch_info(filling.b, nullptr, nullptr, &matrixBytes, nullptr);
+        if (matrixBytes >= (2ull << 30)) finish(filling);
     }
     if (filling.b) finish(filling);
     retire_printed();
