@@ -64,6 +64,18 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
+def pool_record(desc: dict) -> dict:
+    """The matrix pool as dpx_batch_describe reports it: how it was allocated (chunked virtual range or one hipMalloc), the
+    hipMemset time of every candidate allocation the engine timed and which one it kept -- so that a slow run explains itself."""
+    if "pool" not in desc:
+        return None
+    ms = [float(x) for x in str(desc.get("pool_memset_ms", "")).split(",") if x and x != "untimed"]
+    nbytes = int(desc.get("pool_bytes", 0))
+    kept = int(desc.get("pool_kept", 0))
+    return {"mode": desc["pool"], "bytes": nbytes, "chunk_mb": int(desc.get("pool_chunk_mb", 0)), "candidates_ms": ms, "kept": kept,
+            "memset_tbps": round(nbytes / (ms[kept] * 1e-3) / 1e12, 3) if ms else None}
+
+
 def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pairs, shape):
     """Time the reference CPU path on a bounded sample (first `budget_pairs` pairs of this rank's batch)."""
     import numpy as np
@@ -246,6 +258,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    local_kernel_ms = kernel_ms
 
     red_dev = scores_t.device if args.backend == "nccl" else torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -260,9 +273,27 @@ def main():
     ident = [p for p in range(npairs) if (rank * npairs + p) % 101 == 100][:4]
     for p in ident if m else []:
         assert scores[p] == match * min(m, n), "identical pair must score match*len"
+    # Every rank reports its own fill time, pool record and a checksum of its LOCAL scores; rank 0 checks the gathered vector
+    # against every rank's checksum (not only its own slice), so the first run on N real GPUs verifies the collective itself.
+    def checksum(vec) -> int:
+        v = np.asarray(vec, dtype=np.int64)
+        return int((v * (np.arange(v.size, dtype=np.int64) % 1021 + 1)).sum() & 0x7FFFFFFFFFFF)
+
+    mine = {"rank": rank, "device": local_rank, "pairs": int(npairs), "kernel_ms": round(local_kernel_ms, 4),
+            "pool": pool_record(batch.describe()), "scores_checksum": checksum(scores)}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     if world > 1 and rank == 0:  # the gathered vector must carry every rank's scores in rank order
-        assert last is not None and last.numel() == npairs * world
+        assert last is not None and last.numel() == sum(r["pairs"] for r in ranks)
+        g = last.cpu().numpy()
+        off = 0
+        for r in ranks:
+            r["gathered_ok"] = checksum(g[off:off + r["pairs"]]) == r["scores_checksum"]
+            off += r["pairs"]
         assert torch.equal(last[:npairs].cpu(), torch.from_numpy(scores))
+        assert all(r["gathered_ok"] for r in ranks), [r for r in ranks if not r["gathered_ok"]]
 
     if args.dump_scores:
         np.save(f"{args.dump_scores}.rank{rank}.npy", scores)
@@ -297,18 +328,22 @@ def main():
                        "algorithm": algo_name, "pairs_per_gpu": npairs, "query_len": m, "reference_len": n,
                        "match": match, "mismatch": mismatch, "gap": gap_open, "gap_extend": gap_extend if algo_name == "ANW" else None,
                        "parallelism": f"{world} rank(s), 1 per GPU, pairs sharded, RCCL gather of int32 scores" if world > 1 else "1 GPU",
+                       "backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+                       "tune_placement": True,
                        "cells_per_gpu": info["cells"], "matrix_bytes_per_gpu": info["matrix_bytes"],
                        "precondition_fills": precondition_fills, "kernel": desc["kernel"],
                        "rows_per_lane": desc["rows_per_lane"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
-                         "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1)},
+                         "kernel_gcups": round(info["cells"] / (kernel_ms * 1e-3) / 1e9, 1),
+                         "pool": pool_record(desc)},
         }
         if algo_name == "BSW":  # GCUPS counts refLen x queryLen as the reference does; also give the in-band rate
             inband = (info["algorithmic_bytes"] - npairs * (m + n + 28)) // 2
             out["roofline"]["in_band_cells_per_launch"] = inband
             out["roofline"]["in_band_kernel_gcups"] = round(inband / (kernel_ms * 1e-3) / 1e9, 1)
+        out["ranks"] = ranks  # per rank: fill-kernel ms, matrix-pool record, checksum of its scores (+ gathered_ok on rank 0's check)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend,
                                                args.cpu_pairs if m else npairs, shape)

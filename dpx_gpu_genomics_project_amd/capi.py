@@ -17,6 +17,8 @@ KEEP_MATRICES, SCORE_ONLY, TIME_FILLS, TUNE_PLACEMENT = 0x0, 0x1, 0x2, 0x4
 MAT_H, MAT_I, MAT_D = 0, 1, 2
 
 # every symbol include/dpx_align.h declares (tests check the .so exports all of them)
+ABI_VERSION_NEEDED = 2  # include/dpx_align.h DPX_ABI_VERSION: the round-2 entry points + the pool record in dpx_batch_describe
+
 ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_strerror", "dpx_last_error",
     "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_sync",
@@ -91,9 +93,10 @@ def load() -> C.CDLL:
     lib.dpx_batch_destroy.argtypes = [vp]
     lib.dpx_align_batch.argtypes = [C.POINTER(Params), vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     lib.dpx_prim_eval.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp]
-    for name in ABI_SYMBOLS:
-        if getattr(lib, name).restype is C.c_int:
-            pass
+    for name in ABI_SYMBOLS:  # every declared entry point must be exported
+        getattr(lib, name)
+    if lib.dpx_abi_version() < ABI_VERSION_NEEDED:
+        raise DpxError(-8, f"{path} has ABI version {lib.dpx_abi_version()}, this binding needs >= {ABI_VERSION_NEEDED} -- rebuild it")
     _lib = lib
     return lib
 

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -67,9 +68,92 @@ constexpr size_t kLdsFloor = 36u * 1024u * (DPX_FILL_THREADS / 64) / 4;
  * small calls add up when the reference's main.cpp aligns one pair per call from 20 threads.  So nothing a batch
  * allocates is freed when the batch goes away: buffers are parked per kind and handed to the next batch that fits
  * (batched drivers create same-sized batches back to back; the class-per-pair drivers create thousands of tiny ones). */
+/* The matrix pool is not one hipMalloc.  Round 3 (tools/poolstudy.hip, profiles/r03/poolstudy.txt): one hipMalloc of 22 GB is
+ * written by hipMemset at 6.3 TB/s or at 6.05 TB/s and by a streaming-store kernel at 5.5 or 4.8 TB/s depending on the
+ * allocation -- although every single GiB of a "slow" allocation is written as fast as every GiB of a "fast" one, so the
+ * mode is a property of how the runtime backed and mapped the whole range, not of where it lies.  The same range built from
+ * the virtual-memory API -- one hipMemAddressReserve, physical chunks of 1 GiB from hipMemCreate, hipMemMap -- was written at
+ * 6.75 TB/s (memset) / 5.7 TB/s (stores) in every trial, and no chunk size between 16 MiB and 4 GiB showed the slow mode.
+ * So every matrix pool of every caller is a chunked virtual range (DPX_POOL=malloc restores hipMalloc for A/B runs;
+ * DPX_POOL_CHUNK_MB sets the chunk size).  Small pools (< 64 MiB) stay on hipMalloc: the class-per-pair drivers create
+ * thousands of them. */
+struct VmmRange { size_t bytes; int device; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks; };
+std::mutex g_vmmMu;
+std::map<void *, VmmRange> g_vmmRanges;
+struct PoolStats { const char *mode = "malloc"; size_t chunkBytes = 0; }; /* what the last pool_alloc of this thread did */
+thread_local PoolStats t_poolStats;
+
+void vmm_release(void *va, const VmmRange &r, size_t mappedBytes) {
+    if (mappedBytes) (void)hipMemUnmap(va, mappedBytes);
+    for (const auto &c : r.chunks) (void)hipMemRelease(c.first);
+    (void)hipMemAddressFree(va, r.bytes);
+    (void)hipGetLastError();
+}
+
+hipError_t pool_alloc(void **out, size_t bytes) {
+    /* (read on every call, not cached: tools/pool_ab.py alternates the variants inside one process; a pool is allocated once per batch size) */
+    const bool useMalloc = [] { const char *e = getenv("DPX_POOL"); return e && !strcmp(e, "malloc"); }();
+    const size_t chunkEnv = [] { const char *e = getenv("DPX_POOL_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
+    t_poolStats = PoolStats();
+    if (useMalloc || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
+    const size_t gran = (size_t)2 << 20;
+    const size_t chunk = align_up(chunkEnv ? chunkEnv : (size_t)1 << 30, gran);
+    VmmRange r;
+    r.bytes = align_up(bytes, gran);
+    r.device = t_device;
+    void *va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, r.bytes, 0, nullptr, 0);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = t_device;
+    size_t mapped = 0;
+    for (size_t off = 0; off < r.bytes && e == hipSuccess; off += chunk) {
+        const size_t sz = std::min(chunk, r.bytes - off);
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, sz, &prop, 0);
+        if (e != hipSuccess) break;
+        r.chunks.emplace_back(h, sz);
+        e = hipMemMap((char *)va + off, sz, 0, h, 0);
+        if (e == hipSuccess) mapped += sz;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof acc);
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = t_device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, r.bytes, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        vmm_release(va, r, mapped);
+        return e;
+    }
+    { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(va, std::move(r)); }
+    t_poolStats.mode = "vmm";
+    t_poolStats.chunkBytes = chunk;
+    *out = va;
+    return hipSuccess;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    VmmRange r;
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lk(g_vmmMu);
+        auto it = g_vmmRanges.find(p);
+        if (it != g_vmmRanges.end()) { r = std::move(it->second); g_vmmRanges.erase(it); found = true; }
+    }
+    if (found) vmm_release(p, r, r.bytes);
+    else (void)hipFree(p);
+}
+
 class BufCache {
 public:
-    enum Kind { Device, PinnedHost };
+    enum Kind { Device, PinnedHost, DevicePool };
     BufCache(Kind kind, size_t maxEntries, size_t maxBytes) : kind_(kind), maxEntries_(maxEntries), maxBytes_(maxBytes) {}
 
     /* a parked buffer of [need, 1.5 * need + 1 MiB], else a fresh allocation (after an out-of-memory: drop everything
@@ -82,9 +166,13 @@ public:
 private:
     struct Entry { void *ptr; size_t bytes; int device; };
     hipError_t raw_alloc(void **out, size_t bytes) const {
-        return kind_ == Device ? hipMalloc(out, bytes) : hipHostMalloc(out, bytes, hipHostMallocDefault);
+        return kind_ == Device ? hipMalloc(out, bytes) : kind_ == DevicePool ? pool_alloc(out, bytes) : hipHostMalloc(out, bytes, hipHostMallocDefault);
     }
-    void raw_free(void *p) const { if (p) (void)(kind_ == Device ? hipFree(p) : hipHostFree(p)); }
+    void raw_free(void *p) const {
+        if (!p) return;
+        if (kind_ == DevicePool) pool_free(p);
+        else (void)(kind_ == Device ? hipFree(p) : hipHostFree(p));
+    }
     const Kind kind_;
     const size_t maxEntries_, maxBytes_;
     std::mutex mu_;
@@ -164,7 +252,7 @@ void BufCache::drain() {
 }
 
 /* what a batch allocates: the int16 matrices, the arena of small arrays, the traceback line buffers (device + pinned) */
-BufCache g_matCache(BufCache::Device, 64, (size_t)96 << 30), g_arenaCache(BufCache::Device, 64, (size_t)2 << 30),
+BufCache g_matCache(BufCache::DevicePool, 64, (size_t)96 << 30), g_arenaCache(BufCache::Device, 64, (size_t)2 << 30),
     g_tbDevCache(BufCache::Device, 64, (size_t)8 << 30), g_tbHostCache(BufCache::PinnedHost, 64, (size_t)2 << 30);
 
 /* hipStreamCreate / hipStreamDestroy cost ~2 ms each on this stack: a finished batch parks its (idle) stream */
@@ -221,6 +309,18 @@ struct PhaseTrace {
 };
 } // namespace
 
+/* The record of a matrix pool: how it was built and how fast hipMemset writes it (dpx_batch_describe -> bench.py's roofline.pool),
+ * so that a slow run can be attributed to the pool or to something else.  Kept per pool address for the life of the pool (a
+ * parked pool keeps its record for the next batch). */
+struct PoolRecord {
+    std::string mode = "malloc";
+    size_t bytes = 0, chunkBytes = 0;
+    std::vector<float> candidatesMs; /* memset time of every candidate allocation that was timed (empty: never timed) */
+    int kept = 0;
+};
+static std::mutex g_poolRecMu;
+static std::map<void *, PoolRecord> g_poolRecords;
+
 struct dpx_batch {
     int device = -1; /* the device the batch lives on */
     dpx_params prm{};
@@ -247,6 +347,7 @@ struct dpx_batch {
     hipStream_t sideStream = nullptr; /* secondary kernels of a fill run here, concurrently with the main one (launch_all) */
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipEvent_t evT0 = nullptr, evT1 = nullptr; /* DPX_TIME_FILLS: recorded around every dpx_batch_fill() */
+    hipEvent_t evOrder = nullptr;              /* orders the output path behind a fill that ran on a caller's stream */
     bool fillTimed = false;
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
@@ -278,6 +379,7 @@ struct dpx_batch {
     int outState = 0;          /* 0 none, 1 dpx_batch_output_begin() in flight, 2 text on the host */
     uint64_t outFirst = 0;     /* pair number of the batch's first pair in the text */
     size_t nSingles = 0, nCouples = 0, nLanePairs = 0, nWaves = 0; /* launch-list sizes (dpx_batch_describe) */
+    PoolRecord poolRec;    /* how the matrix pool behind dMat was built / timed */
 };
 
 extern "C" {
@@ -496,15 +598,14 @@ static uint64_t band_cells(long long m, long long n, long long B) {
     return (uint64_t)(s1 - s2 + M);
 }
 
-/* Where a big allocation lands in HBM matters: the same 22 GB matrix pool is written at 6.3 TB/s or at 6.05 TB/s by
- * hipMemset depending on the allocation (measured, tools/pool_state.py: two modes, stable for the life of the allocation,
- * and the fill kernels follow it one to one -- the "fast / slow box state" of round 1).  A fresh pool of a GiB or more
- * of a batch created with DPX_TUNE_PLACEMENT is therefore probed: up to six candidate allocations are timed with a memset
- * each, the fastest is kept and parked for every later batch, the others are freed.  Costs the allocations (0.1 - 2 s for tens
- * of GB) + ~10 ms of memsets per candidate, once per process and pool size: for batches that are filled many times. */
-static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace) {
+/* Time the pool with hipMemset (DPX_TUNE_PLACEMENT: callers that fill a resident batch many times; ~2 x 3.5 ms for 22 GB) and,
+ * for pools that are one hipMalloc (DPX_POOL=malloc) or under DPX_POOL_PROBE=2, shop for a better allocation: up to six
+ * candidates, stop when two modes have shown up, keep the fastest (round 2's probe; the chunked virtual range of round 3 has
+ * shown one mode only, so it is timed but not shopped for). */
+static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace, bool shop, PoolRecord &rec) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return first; }
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return first; }
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return first; }
     auto probe = [&](void *p) -> float {
         float best = 1e30f;
         for (int k = 0; k < 2; k++) {
@@ -515,23 +616,25 @@ static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTra
         }
         return best;
     };
-    constexpr int kMaxCand = 6; /* both modes come up about equally often: six candidates miss the fast one in ~2 % of the runs */
+    constexpr int kMaxCand = 6;
     void *cand[kMaxCand] = {first};
     float t[kMaxCand] = {probe(first)};
     int n = 1, bestIdx = 0;
-    for (; n < kMaxCand; n++) {
+    for (; shop && n < kMaxCand; n++) {
         float lo = t[0], hi = t[0];
         for (int k = 1; k < n; k++) { lo = std::min(lo, t[k]); hi = std::max(hi, t[k]); }
         if (n >= 2 && hi > lo * 1.02f) break; /* both modes seen: the fast one is among the candidates */
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; } /* no room to shop around */
-        if (hipMalloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
+        if (pool_alloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
         t[n] = probe(cand[n]);
     }
     for (int k = 1; k < n; k++) if (t[k] < t[bestIdx]) bestIdx = k;
     if (trace.on) for (int k = 0; k < n; k++) fprintf(stderr, "[dpx] pool candidate %d at %p: memset %.3f ms%s\n", k, cand[k], t[k], k == bestIdx ? "  <- kept" : "");
-    for (int k = 0; k < n; k++) if (k != bestIdx && cand[k]) (void)hipFree(cand[k]);
+    for (int k = 0; k < n; k++) if (k != bestIdx && cand[k]) pool_free(cand[k]);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    rec.candidatesMs.assign(t, t + n);
+    rec.kept = bestIdx;
     return cand[bestIdx];
 }
 
@@ -547,6 +650,7 @@ int dpx_batch_destroy(dpx_batch *b) {
     if (b->evT1) (void)hipEventDestroy(b->evT1);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     if (b->evJoin) (void)hipEventDestroy(b->evJoin);
+    if (b->evOrder) (void)hipEventDestroy(b->evOrder);
     g_arenaCache.park(b->arena, b->arenaCap);
     g_matCache.park(b->dMat, b->matPoolBytes);
     g_tbDevCache.park(b->dTb, b->dTbCap);
@@ -893,7 +997,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
      * groups of `group` waves, so a group writes one compact moving window instead of `group` far-apart streams */
     if (b->store) {
         int group = 64;
-        if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 4096) group = v; }
+        if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 1000000) group = v; }
         const uint32_t chunkElems = (banded || b->split) ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
         auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
             if (pd.lanes == 32) return dpx_split_chunks(pd.m, pd.n, b->R);
@@ -973,9 +1077,30 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         /* placement tuning costs up to five more allocations of the pool's size (0.1 - 2 s for tens of GB): only for callers that
          * say the batch is going to be filled many times (DPX_TUNE_PLACEMENT; DPX_POOL_PROBE=1 / 0 forces it on / off) */
         bool tune = (flags & DPX_TUNE_PLACEMENT) != 0;
-        if (const char *env = getenv("DPX_POOL_PROBE")) tune = atoi(env) != 0;
-        if (tune && fresh && b->matPoolBytes >= ((size_t)1 << 30)) pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace);
+        int probeEnv = -1;
+        if (const char *env = getenv("DPX_POOL_PROBE")) { probeEnv = atoi(env); tune = probeEnv != 0; }
+        PoolRecord rec;
+        bool known = false;
+        if (!fresh) {
+            std::lock_guard<std::mutex> lk(g_poolRecMu);
+            auto it = g_poolRecords.find(pool);
+            if (it != g_poolRecords.end()) { rec = it->second; known = true; }
+        }
+        if (!known) {
+            rec.mode = t_poolStats.mode;
+            rec.chunkBytes = t_poolStats.chunkBytes;
+            rec.bytes = b->matPoolBytes;
+        }
+        if (tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30)) {
+            const bool shop = fresh && (probeEnv >= 2 || rec.mode == "malloc");
+            pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace, shop, rec);
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_poolRecMu);
+            g_poolRecords[pool] = rec;
+        }
         b->dMat = (int16_t *)pool;
+        b->poolRec = rec;
 
     }
     trace.mark("create: H2D pairs+matrix pool");
@@ -998,6 +1123,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     a.uniM = numPairs ? b->pairs[0].m : 0;
     a.uniN = numPairs ? b->pairs[0].n : 0;
     a.ldsBufStride = 0;
+    a.rowTags = 0;
     /* big batches are bound by the bytes they write: their ramp steps store only the lines that hold cells (6 % fewer bytes at
      * 1024 x 1024: +3 % LSW, +5 % LNW); small ones are bound by step latency and keep the cheaper whole-chunk stores */
     a.rampLines = numPairs >= 2048 ? 1 : 0;
@@ -1037,6 +1163,15 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
         if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
+        /* SW start cell: one (score, row-in-lane, column) key per pair and lane where score * R + R-1 provably fits 16 bits
+         * (1024 x 1024 at match 3: 3072 * 16 + 15), else one (score, column) key per pair and row (32 more registers at R = 16) */
+        {
+            auto pos = [](long long v) { return v > 0 ? v : 0; };
+            const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
+                                  pos(params->gapOpen) * ((long long)b->maxM + b->maxN); /* fits_int16()'s bound on H */
+            k.rowTags = (kernelAlgo == DPX_ALGO_LSW && top * b->R + b->R - 1 <= 65535) ? 1 : 0;
+            if (const char *env = getenv("DPX_ROW_TAGS")) k.rowTags = (atoi(env) != 0 && k.rowTags) ? 1 : 0; /* A/B runs: 0 = the per-row keys */
+        }
     }
     if (b->lanePacked) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + the staged references of its pairs */
         dpx_fill_args &k = b->pkArgs;
@@ -1238,7 +1373,11 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
     }
     uint64_t *hOff = reinterpret_cast<uint64_t *>(b->hMeta);
     int32_t *hLen = reinterpret_cast<int32_t *>(hOff + np + 1);
-    if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
+    if (b->lastStream && b->lastStream != b->stream) { /* the fill ran on a caller's stream: order behind it without blocking the host */
+        if (!b->evOrder) HIP_TRY(hipEventCreateWithFlags(&b->evOrder, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->evOrder, b->lastStream));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->evOrder, 0));
+    }
     if (!b->tbLinesValid) {
         /* How to walk: one lane per pair -- through register-cached column vectors (walk 1) when there are enough lanes in flight
          * to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster), cell by cell (walk
@@ -1377,9 +1516,17 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
                          : b->packed ? "k_linear_fill_pk" : b->lanePacked ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
-    snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d",
-             names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
-             b->nWaves, b->nSingles, (int)b->args.numStreams);
+    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d",
+                       names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
+                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags);
+    if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
+        const PoolRecord &r = b->poolRec;
+        len += snprintf(buf + len, cap - (size_t)len, " pool=%s pool_bytes=%zu pool_chunk_mb=%zu pool_kept=%d pool_memset_ms=", r.mode.c_str(), b->matPoolBytes,
+                        r.chunkBytes >> 20, r.kept);
+        for (size_t k = 0; k < r.candidatesMs.size() && (size_t)len < cap; k++)
+            len += snprintf(buf + len, cap - (size_t)len, "%s%.3f", k ? "," : "", r.candidatesMs[k]);
+        if (r.candidatesMs.empty() && (size_t)len < cap) len += snprintf(buf + len, cap - (size_t)len, "untimed");
+    }
     return DPX_OK;
 }
 

@@ -35,6 +35,8 @@ typedef struct dpx_fill_args {
     /* stream schedule (uniform batches): wave s of numStreams fills pairs s, s+numStreams, ... back to back */
     int32_t numStreams, uniM, uniN;
     uint32_t ldsBufStride;      /* bytes between the two staged (reference, query) buffers */
+    int32_t rowTags;            /* packed SW kernel: 1 = one (score, row-in-lane, column) key per pair and lane (needs max score * R + R-1 <= 65535),
+                                   0 = one (score, column) key per pair and row */
     int32_t rampLines;          /* 1: skew-ramp steps store only the 128-byte lines that hold cells (byte-bound batches); 0: whole chunks */
 } dpx_fill_args;
 

@@ -1019,7 +1019,29 @@ struct PkState {
     uint32_t rmax[R]; /* SW: per-row running maximum of pair A's key (H << 16 | 0xFFFF - column): max score, then smallest column */
     uint32_t rcol[R]; /* SW: the same for pair B */
     uint32_t dtop;
+    uint32_t keyA, keyB; /* SW, TAGS: ONE key per pair and lane, (H * R + (R-1 - row in lane)) << 16 | 0xFFFF - column: max score, then
+                            smallest row, then smallest column -- the row-major "first strict maximum" of c++/LinearSmithWaterman.cpp:145-157 */
 };
+
+/* per half: H * R + tag on the VOP3P pipe (v_pk_mad_u16 with two inline constants: no register for either) */
+template <int R, int TAG>
+__device__ __forceinline__ uint32_t pk_row_tag(uint32_t h) {
+    static_assert(TAG >= 0 && TAG < R && R <= 16, "inline constants");
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "n"(R), "n"(TAG));
+    return r;
+}
+/* row r of the lane (a constant once the row loop is unrolled: the switch folds away) carries tag R-1 - r */
+template <int R>
+__device__ __forceinline__ uint32_t pk_row_tag_of(uint32_t h, const int r) {
+#define DPX_TAG_CASE(k) case k: if constexpr (k < R) return pk_row_tag<R, (k < R ? R - 1 - k : 0)>(h); else return 0u;
+    switch (r) {
+        DPX_TAG_CASE(0) DPX_TAG_CASE(1) DPX_TAG_CASE(2) DPX_TAG_CASE(3) DPX_TAG_CASE(4) DPX_TAG_CASE(5) DPX_TAG_CASE(6) DPX_TAG_CASE(7)
+        DPX_TAG_CASE(8) DPX_TAG_CASE(9) DPX_TAG_CASE(10) DPX_TAG_CASE(11) DPX_TAG_CASE(12) DPX_TAG_CASE(13) DPX_TAG_CASE(14) DPX_TAG_CASE(15)
+    default: return 0u;
+    }
+#undef DPX_TAG_CASE
+}
 
 __device__ __forceinline__ uint32_t pk_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); } /* {lo.hi16, hi.hi16} */
 
@@ -1049,8 +1071,8 @@ __device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, cons
     }
 }
 
-template <int R, bool LOCAL, bool MASKED, bool WHOLE>
-__device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows,
+template <int R, bool LOCAL, bool MASKED, bool WHOLE, bool TAGS = false, bool PARTIAL = false>
+__device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int lane, const int n, const bool laneHasRows, const int nrows,
                                         const uint32_t matchP, const uint32_t negDeltaP, const uint32_t gapP, const uint32_t e0,
                                         const uint32_t rcP, uint32_t *edge, const bool writeEdge, int16_t *tileA, int16_t *tileB,
                                         const int storeLanes, const int rampLines) {
@@ -1062,6 +1084,7 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
         uint32_t u = upin, d = st.dtop;
         const uint32_t onesP = 0x00010001u;
         const uint32_t negj = 0xFFFFu - (uint32_t)j;
+        uint32_t colMax = 0u; /* TAGS: per half, max over the lane's rows of this column of (H * R + R-1 - r) */
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t left = st.Hl[r];
@@ -1073,13 +1096,23 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
             d = left;
             u = as_u32(h);
             st.Hl[r] = u;
-            if constexpr (LOCAL) {
+            if constexpr (LOCAL && TAGS) {
+                /* the lane's rows are consecutive, so "max score, then first row" inside the lane is one packed maximum over
+                 * (H * R + R-1 - r): v_pk_mad_u16 + v_pk_max_u16 for both pairs (the host guarantees H * R + R-1 <= 65535) */
+                uint32_t tg = pk_row_tag_of<R>(u, r);
+                if constexpr (PARTIAL) tg = (r < nrows) ? tg : 0u; /* rows past the query's end hold no cells */
+                colMax = r == 0 ? tg : dpx::pk_max_u16_raw(colMax, tg);
+            } else if constexpr (LOCAL) {
                 /* first strict maximum of the row, per pair: the int32 kernels' (score, column) key, one per half -- v_and_or_b32 /
                  * v_lshl_or_b32 build it, v_max_u32 (v_max3_u32 across two unrolled steps) folds it: 3-4 ops per two cells where the
                  * packed running-maximum + column select of round 1 took 5 */
                 st.rmax[r] = max(st.rmax[r], (u & 0xFFFF0000u) | negj);
                 st.rcol[r] = max(st.rcol[r], (u << 16) | negj);
             }
+        }
+        if constexpr (LOCAL && TAGS) { /* ... and the column: once per step and pair, not once per row */
+            st.keyA = max(st.keyA, (colMax & 0xFFFF0000u) | negj);
+            st.keyB = max(st.keyB, (colMax << 16) | negj);
         }
         st.dtop = upin;
         if (writeEdge && lane == 63) edge[j] = st.Hl[R - 1];
@@ -1092,7 +1125,7 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
     }
 }
 
-template <int R, bool LOCAL>
+template <int R, bool LOCAL, bool TAGS>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1148,6 +1181,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
             st.rmax[r] = 0u;
             st.rcol[r] = 0u;
         }
+        st.keyA = st.keyB = 0u;
         { const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap); st.dtop = ((uint32_t)b << 16) | b; }
         const size_t csA = prA.chunkStride, csB = prB.chunkStride;
         int16_t *tileA = HpA + (size_t)k * (size_t)n * csA + (size_t)lane * (R < 8 ? R : 8);
@@ -1155,13 +1189,13 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         const uint16_t *rp = refl + 64 - lane;
         uint32_t rcN = rp[0];
         uint32_t e0N = edge[1];
-#define DPX_PK_STEP(MASKED_, WHOLE_, HASROWS_)                                                                                  \
+#define DPX_PK_STEP(MASKED_, WHOLE_, HASROWS_, PARTIAL_)                                                                        \
         {                                                                                                             \
             const uint32_t rc16 = rcN, e0 = e0N;                                                                      \
             rcN = rp[t + 1];                                                                                          \
             e0N = edge[min(t + 2, n + 1)];                                                                            \
             const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u); /* {A char, B char} -> 16-bit lanes */  \
-            pk_step<R, LOCAL, MASKED_, WHOLE_>(st, t, lane, n, HASROWS_, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext, \
+            pk_step<R, LOCAL, MASKED_, WHOLE_, TAGS, PARTIAL_>(st, t, lane, n, HASROWS_, nrows, matchP, negDeltaP, gapP, e0, rcP, edge, hasNext, \
                                        tileA + (size_t)t * csA, tileB + (size_t)t * csB, storeLanes, a.rampLines);   \
         }
         const bool fast = (base + 64 * R <= m) && (n >= 64);
@@ -1169,23 +1203,28 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill_pk(const dpx_f
         if (S == 1) {
             if (fast) {
                 int t = 0;
-                for (; t < 63; t++) DPX_PK_STEP(true, true, true)
-                for (; t + 1 < n;) { DPX_PK_STEP(false, true, true) t++; DPX_PK_STEP(false, true, true) t++; } /* two steps per trip: the keys of both fold with v_max3_u32 */
-                for (; t < n; t++) DPX_PK_STEP(false, true, true)
-                for (; t < W; t++) DPX_PK_STEP(true, true, true)
+                for (; t < 63; t++) DPX_PK_STEP(true, true, true, false)
+                for (; t + 1 < n;) { DPX_PK_STEP(false, true, true, false) t++; DPX_PK_STEP(false, true, true, false) t++; } /* two steps per trip: the keys of both fold with v_max3_u32 */
+                for (; t < n; t++) DPX_PK_STEP(false, true, true, false)
+                for (; t < W; t++) DPX_PK_STEP(true, true, true, false)
             } else {
-                for (int t = 0; t < W; t++) DPX_PK_STEP(true, true, laneHasRows)
+                for (int t = 0; t < W; t++) DPX_PK_STEP(true, true, laneHasRows, true)
             }
         } else if (fast) { /* stripes share their ramp chunks: masked stores on the ramps */
             int t = 0;
-            for (; t < 63; t++) DPX_PK_STEP(true, false, true)
-            for (; t < n; t++) DPX_PK_STEP(false, false, true)
-            for (; t < W; t++) DPX_PK_STEP(true, false, true)
+            for (; t < 63; t++) DPX_PK_STEP(true, false, true, false)
+            for (; t < n; t++) DPX_PK_STEP(false, false, true, false)
+            for (; t < W; t++) DPX_PK_STEP(true, false, true, false)
         } else {
-            for (int t = 0; t < W; t++) DPX_PK_STEP(true, false, laneHasRows)
+            for (int t = 0; t < W; t++) DPX_PK_STEP(true, false, laneHasRows, true)
         }
 #undef DPX_PK_STEP
-        if constexpr (LOCAL) {
+        if constexpr (LOCAL && TAGS) { /* (stripes ascend: a strict '>' keeps the first row holding the maximum) */
+            constexpr int TB = R == 16 ? 4 : R == 8 ? 3 : R == 4 ? 2 : 1;
+            const int hA = (int)(st.keyA >> (16 + TB)), hB = (int)(st.keyB >> (16 + TB));
+            if (hA > bestA) { bestA = hA; browA = row0 + R - (int)((st.keyA >> 16) & (R - 1)); bcolA = 0xFFFF - (int)(st.keyA & 0xFFFFu); }
+            if (hB > bestB) { bestB = hB; browB = row0 + R - (int)((st.keyB >> 16) & (R - 1)); bcolB = 0xFFFF - (int)(st.keyB & 0xFFFFu); }
+        } else if constexpr (LOCAL) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int hA = (int)(st.rmax[r] >> 16), hB = (int)(st.rcol[r] >> 16);
@@ -2499,8 +2538,9 @@ hipError_t launch_linear_R(const dpx_fill_args &a, bool local, bool store, dim3 
 
 template <int R>
 hipError_t launch_linear_pk_R(const dpx_fill_args &a, bool local, dim3 grid, size_t lds, hipStream_t s) {
-    return local ? launch_fill_kernel(k_linear_fill_pk<R, true>, a, grid, lds, s)
-                 : launch_fill_kernel(k_linear_fill_pk<R, false>, a, grid, lds, s);
+    if (!local) return launch_fill_kernel(k_linear_fill_pk<R, false, false>, a, grid, lds, s);
+    return a.rowTags ? launch_fill_kernel(k_linear_fill_pk<R, true, true>, a, grid, lds, s)
+                     : launch_fill_kernel(k_linear_fill_pk<R, true, false>, a, grid, lds, s);
 }
 
 template <int C>

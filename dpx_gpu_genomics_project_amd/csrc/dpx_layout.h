@@ -32,7 +32,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DPX_HD __host__ __device__ __forceinline__
 #else
 #define DPX_HD static inline

@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define DPX_ABI_VERSION 1
+/* 1: round 1.  2: + dpx_batch_create_on, dpx_batch_fill_timed, dpx_batch_last_fill_usec, dpx_batch_output_begin/_end/_take,
+ * dpx_text_free, DPX_TUNE_PLACEMENT (round 2); dpx_batch_describe reports the matrix pool (round 3).  Additions only: a caller
+ * built against version 1 keeps working; dpx_abi_version() >= the version a caller needs is the check. */
+#define DPX_ABI_VERSION 2
 
 typedef enum dpx_status {
     DPX_OK = 0,
@@ -171,7 +174,10 @@ int dpx_text_free(char *text);
 int dpx_batch_info(dpx_batch *b, size_t *numPairs, uint64_t *cells, uint64_t *matrixBytes, uint64_t *algorithmicBytes);
 
 /* One line of text about how the batch will be (was) filled: `algo=LSW kernel_algo=LSW kernel=k_linear_fill_pk dtype=int16
- * rows_per_lane=16 store=1 couples=5000 quad8=0 quad16=0 singles=0 streams=0`.  The reference prints its launch
+ * rows_per_lane=16 store=1 couples=5000 lane_pairs=0 waves=0 singles=0 streams=0 row_tags=1 pool=vmm pool_bytes=22263365632
+ * pool_chunk_mb=1024 pool_kept=0 pool_memset_ms=3.290` (pool_*: how the matrix pool was allocated -- `vmm` = a virtual range
+ * backed by physical chunks, `malloc` = one hipMalloc -- and the hipMemset time of every candidate allocation that was timed,
+ * `untimed` if none was; pool_kept indexes the one in use).  The reference prints its launch
  * geometry the same way (cuda/LNW/LinearNeedlemanWunschV19.cu:398-409); tests and bench.py read the kernel and the
  * arithmetic type from here instead of guessing the host's choice. */
 int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap);

@@ -44,6 +44,12 @@ def test_bench_two_ranks_weak_scaling_rehearsal(tmp_path):
     out, prefix = _torchrun_bench(tmp_path, 2, ["--pairs", "512"])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["metric"] == "GCUPS"
     assert out["config"]["pairs_per_gpu"] == 512 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    # round 3: the line says which backend / world ran and carries every rank's fill time, pool record and score checksum;
+    # rank 0 has checked the gathered vector against EVERY rank's checksum
+    assert out["config"]["backend"] == "gloo" and out["config"]["world_size"] == 2
+    assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["gathered_ok"] and r["kernel_ms"] > 0 and r["pairs"] == 512 for r in out["ranks"])
+    assert out["ranks"][0]["scores_checksum"] != out["ranks"][1]["scores_checksum"]
+    assert out["roofline"]["kernel_ms"] == max(r["kernel_ms"] for r in out["ranks"])
     local = [np.load(f"{prefix}.rank{r}.npy") for r in range(2)]
     gathered = np.load(f"{prefix}.gathered.npy")
     assert np.array_equal(gathered, np.concatenate(local))       # rank order, every rank's own scores
@@ -58,6 +64,7 @@ def test_bench_three_ranks_strong_scaling_shards(tmp_path):
     """configs[4]'s code path (negative pair count = total over all ranks, shard_range per rank), small total."""
     out, prefix = _torchrun_bench(tmp_path, 3, ["--workload", "lsw_100k_1024_sharded", "--total-pairs", "600"])
     assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["config"]["pairs_per_gpu"] == 200
+    assert out["config"]["world_size"] == 3 and len(out["ranks"]) == 3 and all(r["gathered_ok"] for r in out["ranks"])
     gathered = np.load(f"{prefix}.gathered.npy")
     assert len(gathered) == 600
     for r in range(3):

@@ -17,6 +17,7 @@ GROUPS_=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+[ "${PMC_NO_TRAFFIC:-0}" = 1 ] && GROUPS_=("${GROUPS_[@]:0:6}")   # FETCH_SIZE / WRITE_SIZE come from tools/profile_all.sh
 i=0
 for g in "${GROUPS_[@]}"; do
   i=$((i+1))

@@ -14,7 +14,8 @@ for r in $(seq 0 $((W-1))); do
 done
 FAILED=0
 for r in $(seq 0 $((W-1))); do
-  if ! wait "${PIDS[$r]}"; then echo "[rank $r] FAILED (exit status $?)" >&2; cat "$TMP/out.$r" >&2; FAILED=1; fi
+  wait "${PIDS[$r]}"; rc=$?
+  if [ $rc -ne 0 ]; then echo "[rank $r] FAILED (exit status $rc)" >&2; cat "$TMP/out.$r" >&2; FAILED=1; fi
 done
 if [ $FAILED -ne 0 ]; then rm -rf "$TMP"; exit 1; fi
 for r in $(seq 0 $((W-1))); do
