@@ -72,8 +72,10 @@ def pool_record(desc: dict) -> dict:
     ms = [float(x) for x in str(desc.get("pool_memset_ms", "")).split(",") if x and x != "untimed"]
     nbytes = int(desc.get("pool_bytes", 0))
     kept = int(desc.get("pool_kept", 0))
-    return {"mode": desc["pool"], "bytes": nbytes, "chunk_mb": int(desc.get("pool_chunk_mb", 0)), "candidates_ms": ms, "kept": kept,
-            "memset_tbps": round(nbytes / (ms[kept] * 1e-3) / 1e12, 3) if ms else None}
+    fills = [float(x) for x in str(desc.get("pool_fill_ms", "")).split(",") if x and x != "unshopped"]
+    return {"mode": desc["pool"], "bytes": nbytes, "chunk_mb": int(desc.get("pool_chunk_mb", 0)), "candidates_memset_ms": ms,
+            "candidates_fill_ms": fills, "kept": kept,
+            "memset_tbps": round(nbytes / (ms[kept] * 1e-3) / 1e12, 3) if len(ms) > kept and ms[kept] > 0 else None}
 
 
 def cpu_baseline(sb, algo_name, match, mismatch, gap_open, gap_extend, budget_pairs, shape):

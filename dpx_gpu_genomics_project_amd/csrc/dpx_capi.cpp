@@ -72,10 +72,11 @@ constexpr size_t kLdsFloor = 36u * 1024u * (DPX_FILL_THREADS / 64) / 4;
  * written by hipMemset at 6.3 TB/s or at 6.05 TB/s and by a streaming-store kernel at 5.5 or 4.8 TB/s depending on the
  * allocation -- although every single GiB of a "slow" allocation is written as fast as every GiB of a "fast" one, so the
  * mode is a property of how the runtime backed and mapped the whole range, not of where it lies.  The same range built from
- * the virtual-memory API -- one hipMemAddressReserve, physical chunks of 1 GiB from hipMemCreate, hipMemMap -- was written at
- * 6.75 TB/s (memset) / 5.7 TB/s (stores) in every trial, and no chunk size between 16 MiB and 4 GiB showed the slow mode.
- * So every matrix pool of every caller is a chunked virtual range (DPX_POOL=malloc restores hipMalloc for A/B runs;
- * DPX_POOL_CHUNK_MB sets the chunk size).  Small pools (< 64 MiB) stay on hipMalloc: the class-per-pair drivers create
+ * the virtual-memory API -- one hipMemAddressReserve, physical chunks from hipMemCreate, hipMemMap -- was written at 6.5 - 7.2 TB/s
+ * (memset) in every trial, and the headline fill follows: 3.62 ms on one hipMalloc, 3.2 - 3.35 ms on 256-MiB chunks (eight fresh
+ * pools each, alternating in one process, profiles/r03/pool_ab_variants_*.txt; 1-GiB and 2-MiB chunks: wider spread, 3.28 - 3.61).
+ * So every matrix pool of every caller is a chunked virtual range of 256-MiB chunks (DPX_POOL=malloc restores hipMalloc for
+ * A/B runs; DPX_POOL_CHUNK_MB sets the chunk size).  Small pools (< 64 MiB) stay on hipMalloc: the class-per-pair drivers create
  * thousands of them. */
 struct VmmRange { size_t bytes; int device; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks; };
 std::mutex g_vmmMu;
@@ -97,7 +98,7 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     t_poolStats = PoolStats();
     if (useMalloc || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
     const size_t gran = (size_t)2 << 20;
-    const size_t chunk = align_up(chunkEnv ? chunkEnv : (size_t)1 << 30, gran);
+    const size_t chunk = align_up(chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
     VmmRange r;
     r.bytes = align_up(bytes, gran);
     r.device = t_device;
@@ -315,7 +316,8 @@ struct PhaseTrace {
 struct PoolRecord {
     std::string mode = "malloc";
     size_t bytes = 0, chunkBytes = 0;
-    std::vector<float> candidatesMs; /* memset time of every candidate allocation that was timed (empty: never timed) */
+    std::vector<float> candidatesMs; /* hipMemset time of every candidate allocation (empty: never timed) */
+    std::vector<float> fillMs;       /* time of one fill of the batch on every candidate (empty: never shopped) */
     int kept = 0;
 };
 static std::mutex g_poolRecMu;
@@ -357,6 +359,8 @@ struct dpx_batch {
     size_t streamLds = 0;
     bool packed = false;
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
+    bool splitPk = false;  /* ... two equal-shaped pairs per workgroup on the packed-int16 pipe (k_linear_split_pk); leftovers on k_linear_split */
+    size_t splitPkLds = 0;
     int splitWaves = 0;
     size_t splitLds = 0;
     bool lanePacked = false; /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
@@ -380,6 +384,7 @@ struct dpx_batch {
     uint64_t outFirst = 0;     /* pair number of the batch's first pair in the text */
     size_t nSingles = 0, nCouples = 0, nLanePairs = 0, nWaves = 0; /* launch-list sizes (dpx_batch_describe) */
     PoolRecord poolRec;    /* how the matrix pool behind dMat was built / timed */
+    bool tunePool = false, tuneShop = false; /* DPX_TUNE_PLACEMENT: the pool is timed / shopped for at the end of dpx_batch_create */
 };
 
 extern "C" {
@@ -598,44 +603,70 @@ static uint64_t band_cells(long long m, long long n, long long B) {
     return (uint64_t)(s1 - s2 + M);
 }
 
-/* Time the pool with hipMemset (DPX_TUNE_PLACEMENT: callers that fill a resident batch many times; ~2 x 3.5 ms for 22 GB) and,
- * for pools that are one hipMalloc (DPX_POOL=malloc) or under DPX_POOL_PROBE=2, shop for a better allocation: up to six
- * candidates, stop when two modes have shown up, keep the fastest (round 2's probe; the chunked virtual range of round 3 has
- * shown one mode only, so it is timed but not shopped for). */
-static void *pick_well_placed(void *first, size_t bytes, hipStream_t s, PhaseTrace &trace, bool shop, PoolRecord &rec) {
+/* hipMemset time of a pool (the record of a pool that a resident-batch caller is going to fill many times; 2 x 3.5 ms for 22 GB) */
+static float time_memset(void *p, size_t bytes, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return first; }
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return first; }
-    auto probe = [&](void *p) -> float {
-        float best = 1e30f;
-        for (int k = 0; k < 2; k++) {
-            float ms = 1e30f;
-            if (hipEventRecord(e0, s) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
-                hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
-            best = std::min(best, ms);
-        }
-        return best;
-    };
-    constexpr int kMaxCand = 6;
-    void *cand[kMaxCand] = {first};
-    float t[kMaxCand] = {probe(first)};
-    int n = 1, bestIdx = 0;
-    for (; shop && n < kMaxCand; n++) {
-        float lo = t[0], hi = t[0];
-        for (int k = 1; k < n; k++) { lo = std::min(lo, t[k]); hi = std::max(hi, t[k]); }
-        if (n >= 2 && hi > lo * 1.02f) break; /* both modes seen: the fast one is among the candidates */
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; } /* no room to shop around */
-        if (pool_alloc(&cand[n], bytes) != hipSuccess) { (void)hipGetLastError(); cand[n] = nullptr; break; }
-        t[n] = probe(cand[n]);
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return -1.f; }
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return -1.f; }
+    float best = 1e30f;
+    for (int k = 0; k < 2; k++) {
+        float ms = 1e30f;
+        if (hipEventRecord(e0, s) != hipSuccess || hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
+            hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); best = -1.f; break; }
+        best = std::min(best, ms);
     }
-    for (int k = 1; k < n; k++) if (t[k] < t[bestIdx]) bestIdx = k;
-    if (trace.on) for (int k = 0; k < n; k++) fprintf(stderr, "[dpx] pool candidate %d at %p: memset %.3f ms%s\n", k, cand[k], t[k], k == bestIdx ? "  <- kept" : "");
-    for (int k = 0; k < n; k++) if (k != bestIdx && cand[k]) pool_free(cand[k]);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    rec.candidatesMs.assign(t, t + n);
-    rec.kept = bestIdx;
-    return cand[bestIdx];
+    return best;
+}
+
+static hipError_t launch_all(dpx_batch *b, hipStream_t s);
+
+/* DPX_TUNE_PLACEMENT (callers that fill a resident batch many times: bench.py, iterative drivers).  The same fill runs up to
+ * 27 % apart on two pools of the same construction (ANW 1000 x 1024^2: 1.05 vs 1.20 ms, alternating from one allocation to the
+ * next while hipMemset sees no difference; LSW 10k x 1024^2: +-2 %; tools/mode_watch.py, profiles/r03/): the mode belongs to the
+ * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: up to
+ * four candidate pools, one warm-up + three timed fills each, the fastest is kept (and parked for later batches), the loser of
+ * every comparison is freed at once (never more than two pools alive).  Stops early once two candidates differ by more than 3 %
+ * (both modes seen).  Every candidate's times go into the pool record (dpx_batch_describe -> bench.py roofline.pool). */
+static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return; }
+    auto set_pool = [&](void *p) { b->dMat = (int16_t *)p; b->args.mat = b->dMat; b->pkArgs.mat = b->dMat; };
+    auto time_fill = [&]() -> float {
+        float ms = -1.f;
+        hipError_t e = launch_all(b, b->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, b->stream);
+        for (int i = 0; i < 3 && e == hipSuccess; i++) e = launch_all(b, b->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, b->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -1.f; }
+        return ms / 3.f;
+    };
+    const size_t bytes = b->matPoolBytes;
+    void *best = b->dMat;
+    float bestMs = time_fill();
+    rec.fillMs.assign(1, bestMs);
+    rec.kept = 0;
+    float lo = bestMs, hi = bestMs;
+    for (int k = 1; k < 4 && bestMs > 0.f; k++) {
+        if (k >= 2 && hi > lo * 1.03f) break; /* both modes seen */
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; }
+        void *cand = nullptr;
+        if (pool_alloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        set_pool(cand);
+        const float ms = time_fill();
+        rec.fillMs.push_back(ms);
+        rec.candidatesMs.push_back(time_memset(cand, bytes, b->stream));
+        if (ms > 0.f) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
+        if (ms > 0.f && ms < bestMs) { pool_free(best); best = cand; bestMs = ms; rec.kept = k; }
+        else pool_free(cand);
+    }
+    set_pool(best);
+    if (trace.on) for (size_t k = 0; k < rec.fillMs.size(); k++) fprintf(stderr, "[dpx] pool candidate %zu: fill %.3f ms%s\n", k, rec.fillMs[k], (int)k == rec.kept ? "  <- kept" : "");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
 int dpx_batch_destroy(dpx_batch *b) {
@@ -903,6 +934,44 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             b->splitWaves = sW;
             b->splitLds = lds;
             for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 32; b->pairs[i].rows = (uint16_t)sR; }
+            /* packed split kernel (round 3): couples of equal-shaped pairs, two per workgroup on the VOP3P pipe -- half the vector
+             * instructions per cell of a kernel that is bound by its instruction stream.  Needs the 16-bit wrapping adds to be safe
+             * (packed_safe) and, for SW, (score * R + R-1) to fit 16 bits (the row-tag keys).  DPX_SPLIT_PK=0/1 overrides. */
+            dpx_params kp = *params;
+            kp.algo = kernelAlgo;
+            auto pos = [](long long v) { return v > 0 ? v : 0; };
+            const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
+                                  pos(params->gapOpen) * ((long long)b->maxM + b->maxN);
+            const size_t edgePk = align_up((size_t)b->maxN + 2, 4); /* uint32 elements */
+            const size_t ldsPk = 1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgePk * 4;
+            bool splitPk = numPairs >= 2 && packed_safe(kp, b->maxM, b->maxN) && (kernelAlgo != DPX_ALGO_LSW || top * sR + sR - 1 <= 65535) &&
+                           ldsPk <= 160u * 1024u;
+            if (const char *env = getenv("DPX_SPLIT_PK")) splitPk = splitPk && atoi(env) != 0;
+            if (splitPk) {
+                std::vector<int32_t> idx(numPairs);
+                std::iota(idx.begin(), idx.end(), 0);
+                if (ragged)
+                    std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) {
+                        const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
+                        const uint64_t cx = (uint64_t)X.m * X.n, cy = (uint64_t)Y.m * Y.n;
+                        if (cx != cy) return cx > cy;
+                        if (X.m != Y.m) return X.m > Y.m;
+                        return X.n > Y.n;
+                    });
+                for (size_t i = 0; i < idx.size();) {
+                    if (i + 1 < idx.size() && b->pairs[idx[i]].m == b->pairs[idx[i + 1]].m && b->pairs[idx[i]].n == b->pairs[idx[i + 1]].n) {
+                        couples.push_back(idx[i]);
+                        couples.push_back(idx[i + 1]);
+                        i += 2;
+                    } else {
+                        singles.push_back(idx[i]);
+                        i += 1;
+                    }
+                }
+                b->splitPk = !couples.empty();
+                if (!b->splitPk) singles.clear();
+                b->splitPkLds = ldsPk;
+            }
         }
     }
     trace.mark("create: validate+geometry+launch lists");
@@ -948,7 +1017,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     if (b->lanePacked) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, waves.data(), waves.size() * sizeof(dpx_wave_desc), hipMemcpyHostToDevice));
-    } else if (b->packed) {
+    } else if (b->packed || b->splitPk) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     } else if (ragged) {
@@ -962,7 +1031,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         b->dOrder = arenaOrder;
         CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    const size_t numSingles = (b->packed || b->lanePacked) ? singles.size() : numPairs;
+    const size_t numSingles = (b->packed || b->lanePacked || b->splitPk) ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
     /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
@@ -1004,6 +1073,8 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
         };
         uint64_t off = 0;
+        uint64_t groupPadElems = 0; /* experiment: int16 elements left free behind every group's block (DPX_GROUP_PAD_KB) */
+        if (const char *env = getenv("DPX_GROUP_PAD_KB")) groupPadElems = (uint64_t)std::max(0, atoi(env)) * 512u;
         auto place = [&](const std::vector<int32_t> &slots, size_t slotsPerGroup, uint32_t chunkElems) { /* slots in launch order */
             for (size_t s0 = 0; s0 < slots.size(); s0 += slotsPerGroup) {
                 const size_t cnt = std::min(slotsPerGroup, slots.size() - s0);
@@ -1014,7 +1085,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
                     pd.matOff = off + (uint64_t)g * chunkElems;
                     pd.chunkStride = (uint32_t)(cnt * chunkElems);
                 }
-                off += maxChunks * (uint64_t)cnt * chunkElems;
+                off += maxChunks * (uint64_t)cnt * chunkElems + groupPadElems;
             }
         };
         if (b->streamed) {
@@ -1035,7 +1106,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
                 }
                 off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
             }
-        } else if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave = two adjacent slots */
+        } else if (b->packed || b->splitPk) place(couples, (size_t)group * 2, chunkElems); /* one wave (workgroup) = two adjacent slots */
         else if (b->lanePacked) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
             const uint32_t stepElems = dpx_wtile_step_elems(b->R / 8, b->planes);
             for (const dpx_wave_desc &wd : waves) {
@@ -1051,7 +1122,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             }
         }
         if (b->streamed) {
-        } else if (b->packed || b->lanePacked || !singles.empty()) {
+        } else if (b->packed || b->lanePacked || b->splitPk || !singles.empty()) {
             place(singles, (size_t)group, chunkElems);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
@@ -1074,8 +1145,9 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         void *pool = nullptr;
         bool fresh = false;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes, &fresh));
-        /* placement tuning costs up to five more allocations of the pool's size (0.1 - 2 s for tens of GB): only for callers that
-         * say the batch is going to be filled many times (DPX_TUNE_PLACEMENT; DPX_POOL_PROBE=1 / 0 forces it on / off) */
+        /* DPX_TUNE_PLACEMENT (callers that fill the batch many times): the pool is timed with hipMemset and, if it is a fresh one,
+         * shopped for with the batch's own fill at the end of this function (shop_pool_by_fill: up to three more allocations of the
+         * pool's size).  DPX_POOL_PROBE=0 / 1 / 2 forces nothing / timing only / timing + shopping, whatever the flag says */
         bool tune = (flags & DPX_TUNE_PLACEMENT) != 0;
         int probeEnv = -1;
         if (const char *env = getenv("DPX_POOL_PROBE")) { probeEnv = atoi(env); tune = probeEnv != 0; }
@@ -1091,16 +1163,12 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             rec.chunkBytes = t_poolStats.chunkBytes;
             rec.bytes = b->matPoolBytes;
         }
-        if (tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30)) {
-            const bool shop = fresh && (probeEnv >= 2 || rec.mode == "malloc");
-            pool = pick_well_placed(pool, b->matPoolBytes, b->stream, trace, shop, rec);
-        }
-        {
-            std::lock_guard<std::mutex> lk(g_poolRecMu);
-            g_poolRecords[pool] = rec;
-        }
+        b->tunePool = tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30);
+        b->tuneShop = b->tunePool && fresh && probeEnv != 1; /* DPX_POOL_PROBE=1: time only, no shopping */
+        if (b->tunePool) rec.candidatesMs.assign(1, time_memset(pool, b->matPoolBytes, b->stream));
         b->dMat = (int16_t *)pool;
         b->poolRec = rec;
+        { std::lock_guard<std::mutex> lk(g_poolRecMu); g_poolRecords[pool] = rec; }
 
     }
     trace.mark("create: H2D pairs+matrix pool");
@@ -1184,16 +1252,32 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if ((b->packed || b->lanePacked) && numSingles > 0) {
+    if (b->splitPk) { /* packed split kernel: 1 KiB of control, 2-byte reference entries, 4-byte edge entries */
+        dpx_fill_args &k = b->pkArgs;
+        k = a;
+        k.order = b->dCouples;
+        k.numPairs = (int32_t)numCouples;
+        k.ldsRefOff = 1024u;
+        k.ldsQryOff = (uint32_t)(1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16));
+        k.ldsBufStride = (uint32_t)align_up((size_t)b->maxN + 2, 4);
+        b->pkLdsBytes = b->splitPkLds;
+    }
+    if ((b->packed || b->lanePacked || b->splitPk) && numSingles > 0) {
         /* more than one kernel per fill: a side stream + fork/join events (failure here only costs the overlap) */
         if (stream_take(&b->sideStream) != hipSuccess) { b->sideStream = nullptr; (void)hipGetLastError(); }
         if (b->sideStream && (hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&b->evJoin, hipEventDisableTiming) != hipSuccess)) (void)hipGetLastError();
     }
     b->nSingles = numSingles;
-    b->nCouples = b->packed ? numCouples : 0;
+    b->nCouples = (b->packed || b->splitPk) ? numCouples : 0;
     b->nLanePairs = b->lanePacked ? lanesPairs : 0;
     b->nWaves = b->lanePacked ? waves.size() : 0;
+    if (b->tuneShop && b->dMat) {
+        shop_pool_by_fill(b, b->poolRec, trace);
+        std::lock_guard<std::mutex> lk(g_poolRecMu);
+        g_poolRecords[b->dMat] = b->poolRec;
+        trace.mark("create: pool shopped by fill");
+    }
     *out = b;
     return DPX_OK;
 }
@@ -1208,6 +1292,7 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     int kernels = 0;
     if (b->packed) kernels++;
     if (b->lanePacked) kernels++;
+    if (b->splitPk) kernels++;
     if (hasMain) kernels++;
     hipStream_t side = s;
     bool forked = false;
@@ -1227,6 +1312,9 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
         if (e == hipSuccess) e = b->kernelAlgo == DPX_ALGO_BSW ? dpx_launch_banded_packed(b->pkArgs, b->R, b->pkLdsBytes, s)
                                                                : dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
+    } else if (b->splitPk) {
+        if (hasMain) e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, side); /* leftover singles */
+        if (e == hipSuccess) e = dpx_launch_fill_split_packed(b->pkArgs, b->kernelAlgo, b->R, b->splitWaves, b->pkLdsBytes, s);
     } else if (b->split) {
         e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, s);
     } else if (b->streamed) {
@@ -1514,10 +1602,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->lanePacked ? "k_linear_lanes" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+                         : b->packed ? "k_linear_fill_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d",
-                       names[b->prm.algo], names[b->kernelAlgo], kernel, b->packed ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
+                       names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
                        b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags);
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;
@@ -1526,6 +1614,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
         for (size_t k = 0; k < r.candidatesMs.size() && (size_t)len < cap; k++)
             len += snprintf(buf + len, cap - (size_t)len, "%s%.3f", k ? "," : "", r.candidatesMs[k]);
         if (r.candidatesMs.empty() && (size_t)len < cap) len += snprintf(buf + len, cap - (size_t)len, "untimed");
+        if ((size_t)len < cap) len += snprintf(buf + len, cap - (size_t)len, " pool_fill_ms=");
+        for (size_t k = 0; k < r.fillMs.size() && (size_t)len < cap; k++)
+            len += snprintf(buf + len, cap - (size_t)len, "%s%.3f", k ? "," : "", r.fillMs[k]);
+        if (r.fillMs.empty() && (size_t)len < cap) len += snprintf(buf + len, cap - (size_t)len, "unshopped");
     }
     return DPX_OK;
 }

@@ -103,10 +103,10 @@ def test_config4_one_rank_shard_of_lsw_100k_1024_at_full_size(gpu):
             o = O.lsw(sb.ref(p), sb.qry(p), *W)
             assert np.array_equal(b.matrix(p).astype(np.int32), o.H)
             assert b.traceback(p) == (("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o))
-    # a pair's result does not depend on the shard around it: a sample alone, on another kernel (int32, one wave per stripe)
+    # a pair's result does not depend on the shard around it: a sample alone, on another kernel (one wave per stripe)
     sample = np.arange(3, hi - lo, 997)
     with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs[sample], *W) as small:
-        assert small.describe()["kernel"] == "k_linear_split"
+        assert small.describe()["kernel"].startswith("k_linear_split")
         small.fill()
         s1, r1, c1 = small.results()
     assert np.array_equal(s1, sc[sample]) and np.array_equal(r1, er[sample]) and np.array_equal(c1, ec[sample])
