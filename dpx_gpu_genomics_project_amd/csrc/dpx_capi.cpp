@@ -190,7 +190,10 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual, bool *fresh) 
         size_t best = parked_.size();
         for (size_t i = 0; i < parked_.size(); i++) {
             const Entry &e = parked_[i];
-            if (e.device != t_device || e.bytes < need || e.bytes > need + need / 2 + (1u << 20)) continue;
+            /* (a parked matrix pool of up to 13 GiB serves any smaller batch: a driver that cuts a file into batches of one pool
+             * budget ends with a short batch, and a pool reserved ahead of time -- dpx_pool_reserve -- is sized by the budget) */
+            const size_t roof = kind_ == DevicePool ? std::max(need + need / 2 + (1u << 20), (size_t)13 << 30) : need + need / 2 + (1u << 20);
+            if (e.device != t_device || e.bytes < need || e.bytes > roof) continue;
             if (best == parked_.size() || e.bytes < parked_[best].bytes) best = i;
         }
         if (best != parked_.size()) {
@@ -224,11 +227,14 @@ void BufCache::park(void *ptr, size_t bytes) {
         if (t_device < 0 || bytes > maxBytes_) {
             evicted.push_back(ptr);
         } else {
-            const size_t big = (size_t)1 << 30; /* at most one parked buffer of a GiB or more per device */
-            for (size_t i = 0; i < parked_.size();) {
-                const bool drop = bytes >= big && parked_[i].bytes >= big && parked_[i].device == t_device; /* per device */
+            /* per device: at most one parked buffer of 16 GiB or more, at most two of a GiB or more (two batches in flight on
+             * two pools of a few GiB each is the shape of a pipelined driver; tens of GB twice over is not worth holding) */
+            const size_t big = (size_t)1 << 30, huge = (size_t)16 << 30;
+            size_t bigOnes = 0;
+            for (size_t i = parked_.size(); i-- > 0;) { /* newest first: the oldest go */
+                if (parked_[i].device != t_device || parked_[i].bytes < big || bytes < big) continue;
+                const bool drop = bytes >= huge || parked_[i].bytes >= huge || ++bigOnes >= 2;
                 if (drop) { evicted.push_back(parked_[i].ptr); total_ -= parked_[i].bytes; parked_.erase(parked_.begin() + (long)i); }
-                else i++;
             }
             while (!parked_.empty() && (parked_.size() >= maxEntries_ || total_ + bytes > maxBytes_)) {
                 evicted.push_back(parked_.front().ptr);
@@ -460,6 +466,24 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
     if (name && nameCap) { snprintf(name, nameCap, "%s (%s)", prop.name, prop.gcnArchName); }
     if (computeUnits) *computeUnits = prop.multiProcessorCount;
     if (hbmBytes) *hbmBytes = prop.totalGlobalMem;
+    return DPX_OK;
+}
+
+/* Allocate `count` matrix pools of `bytes` on the default device and park them for the batches to come.  A driver calls this
+ * on a helper thread while it is still parsing its input: building a pool costs tens of ms per GiB (the reference's V9 / V14
+ * lesson: size the buffers once, outside the loop -- cuda/LNW/LinearNeedlemanWunschV9.cu:26-46, V14.cu:144-213). */
+int dpx_pool_reserve(size_t bytes, int count) {
+    if (count < 1 || count > 2 || bytes == 0) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    void *p[2] = {nullptr, nullptr};
+    size_t got[2] = {0, 0};
+    for (int k = 0; k < count; k++) {
+        bool fresh = false;
+        hipError_t e = g_matCache.take(&p[k], bytes, &got[k], &fresh);
+        if (e != hipSuccess) { for (int j = 0; j < k; j++) g_matCache.park(p[j], got[j]); return hip_fail(e, "dpx_pool_reserve"); }
+    }
+    for (int k = 0; k < count; k++) g_matCache.park(p[k], got[k]);
     return DPX_OK;
 }
 
@@ -1474,6 +1498,10 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
          * path (5000 x 1024^2: 1.60 vs 1.83 ms LSW, 1.50 vs 1.53 LNW; 20k x 300^2: 1.30 vs 0.65 ms; 100k short reads: 2.1 vs
          * 0.59 ms).  DPX_TB_WALK=0/1/2 forces one. */
         int walk = b->numPairs >= 65536 ? 1 : 0;
+        /* long paths on layouts with 8-row column vectors: one wave per pair through an LDS window, one HBM round trip per ~32
+         * path steps instead of one per step (round 2: 5000 x 1024^2 LSW 1.60 vs 1.83 ms; loses below ~1000-step paths) */
+        if (b->maxM + b->maxN >= 1500 && b->numPairs < 65536 && !b->split && b->R >= 8 &&
+            (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW)) walk = 2;
         if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
         else if (const char *env = getenv("DPX_TB_CACHED")) walk = atoi(env) != 0 ? 1 : 0; /* (round-1 knob, tests) */
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));

@@ -581,6 +581,32 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+/* The cell update of the lane-packed linear kernels (round 3).  The lane's state is kept as Hg = H + gap: then
+ *     H[r][j] = max3(Hg[r-1][j], Hg[r][j-1], Hg[r-1][j-1] + (s - gap))          (one v_max3_i32, SW: the diagonal term clamped at 0 first)
+ * and Hg[r][j] = H[r][j] + gap is the only op left on the chain from one row to the next: 5 vector instructions per NW cell
+ * instead of 6 (v_cmp, v_cndmask, v_add, v_max3, v_add), two dependent ones per row instead of three.  The diagonal terms are
+ * computed first and every row is updated in place (no register rotation, see lin_cells).  h[] returns the plain scores. */
+template <int R, bool LOCAL>
+__device__ __forceinline__ void lin_cells_g(LinState<R, LOCAL> &st, const int upinG, const int rc, const unsigned negj, const int matchG,
+                                            const int mismatchG, const int gap, int (&h)[R]) {
+    int dterm[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        dterm[r] = ((r == 0) ? st.dtop : st.Hl[r - 1]) + ((st.qc[r] == rc) ? matchG : mismatchG);
+        if constexpr (LOCAL) dterm[r] = max(dterm[r], 0);
+    }
+    int ug = upinG;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int v = max(max(ug, st.Hl[r]), dterm[r]); /* v_max3_i32 */
+        h[r] = v;
+        ug = v + gap;
+        st.Hl[r] = ug;
+        if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)v << 16) | negj);
+    }
+    st.dtop = upinG;
+}
+
 template <int R, bool LOCAL, bool STORE>
 __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -595,7 +621,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
     const int p = sl.p, l = sl.l;
     const dpx_pair_dev pr = a.pairs[p];
     const int n = has ? pr.n : 0, m = has ? pr.m : 0;
-    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    const int gap = a.gapOpen, matchG = a.match - gap, mismatchG = a.mismatch - gap;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
@@ -606,65 +632,115 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
-    LinState<R, LOCAL> st;
+    LinState<R, LOCAL> st; /* Hl = H + gap, dtop = H[row0][j-1] + gap (lin_cells_g) */
     load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+        st.Hl[r] = (LOCAL ? 0 : (row0 + 1 + r) * gap) + gap;
         st.key[r] = 0u;
     }
-    st.dtop = LOCAL ? 0 : row0 * gap;
+    st.dtop = (LOCAL ? 0 : row0 * gap) + gap;
 
     const int skew = l + sl.d; /* this lane runs column j = t - skew + 1 in step t */
     const int n8 = (n + 7) & ~7;
     const int LB = (int)dpx_tile8_row_blocks(m);
-    if constexpr (STORE) Stage::set_route(tileL, lane, skew, n8, has ? min(max(LB - l * Q, 0), Q) : 0);
+    /* Routing.  A lane's line (8 columns x 8 rows, 128 B) is complete in the steps t = skew + 7, skew + 15, ... <= n8 + skew - 1, and
+     * skew = lane (mod 8): in step t the lines of the lanes (t+1) mod 8 of every 8-lane group are complete, whatever pairs they
+     * belong to.  Every lane publishes (first step | last step << 16) and the number of its row blocks that hold rows once, in the
+     * 16 spare bytes of its LDS line; every lane then keeps the words of the eight lanes of its group in registers -- the loop reads
+     * no routing from LDS (round 2 fetched one word per step) and decides with two compares. */
+    uint32_t rt[8], nv[8];
+    if constexpr (STORE) {
+        const int nValid = has ? min(max(LB - l * Q, 0), Q) : 0;
+        uint32_t *mine = reinterpret_cast<uint32_t *>(tileL + lane * kStageLine + 128);
+        mine[0] = nValid > 0 ? ((uint32_t)(skew + 7) | ((uint32_t)(n8 + skew - 1) << 16)) : 0x00007FFFu; /* (never valid: first > last) */
+        mine[1] = (uint32_t)nValid;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t *o = reinterpret_cast<const uint32_t *>(tileL + ((lane & ~7) | k) * kStageLine + 128);
+            rt[k] = o[0];
+            nv[k] = o[1];
+        }
+    }
     /* the wave's stream of chunks (dpx_layout.h): every pair of the wave carries the same base; lane 0 always belongs to slot 0 */
     int16_t *waveBase = a.mat + (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff >> 32)) << 32) |
                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff & 0xFFFFFFFFull)));
-    const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
+    const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (STORE ? n8 : n) + skew : 0)); /* uniform: the loop runs on the scalar unit */
     const unsigned char *rp = refs - skew; /* rp[t] = reference character of column j = t - skew + 1 */
+    const unsigned nEff = nrows > 0 ? (unsigned)n : 0u; /* the lane is on a cell iff (unsigned)(t - skew) < nEff */
+    unsigned char *putPtr = tileL + lane * kStageLine;             /* + sub-tile * 64 lines + (t & 7) * 16 */
+    const unsigned char *fetchPtr[8];                              /* piece lane % 8 of the line of lane k of this lane's group, rotated by its owner */
+#pragma unroll
+    for (int k = 0; k < 8; k++) fetchPtr[k] = tileL + ((lane & ~7) | k) * kStageLine + (((lane + k) & 7) << 4);
+    u32x4 pend[Q];
+    int pendN = 0;
+    int16_t *pendDst = nullptr;
+    int bordG = (2 - skew) * gap; /* NW, first lane of a slot: H[0][j] + gap = (j + 1) * gap, j = t - skew + 1 */
     int rcN = rp[0];
-    Stage stage;
-    if constexpr (STORE) stage.fetch_route(tileL, lane, 0);
-    auto lane_step = [&](const int t) {
-        const int j = t - skew + 1;
+    auto flush = [&]() __attribute__((always_inline)) { /* write out the lines read one step ago */
+#pragma unroll
+        for (int hq = 0; hq < Q; hq++)
+            if (hq < pendN) stream_store(reinterpret_cast<u32x4 *>(pendDst + (hq << 9)), pend[hq]);
+    };
+    auto lane_step = [&](const int t, auto kTag) __attribute__((always_inline)) {
+        constexpr int K = decltype(kTag)::value; /* t & 7 */
+        const int tms = t - skew;
         const int rc = rcN;
         rcN = rp[t + 1];
         const int sh = wave_shr1(st.Hl[R - 1], 0);
-        const int upin = (l == 0) ? (LOCAL ? 0 : j * gap) : sh; /* a slot's first lane: row-0 border of its column */
-        const bool active = nrows > 0 && j >= 1 && j <= n;
-        if (active) lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
-        if constexpr (STORE) {
-            if (active) {
-                uint32_t wd[(R + 1) / 2];
-                lin_pack<R, LOCAL>(st, wd);
+        const int upinG = (l == 0) ? (LOCAL ? gap : bordG) : sh; /* a slot's first lane: row-0 border of its column (+ gap) */
+        if constexpr (!LOCAL) bordG += gap;
+        if ((unsigned)tms < nEff) {
+            int h[R];
+            lin_cells_g<R, LOCAL>(st, upinG, rc, 0xFFFEu - (unsigned)tms, matchG, mismatchG, gap, h);
+            if constexpr (STORE) {
 #pragma unroll
-                for (int h = 0; h < Q; h++) {
-                    u32x4 v = {wd[4 * h + 0], wd[4 * h + 1], wd[4 * h + 2], wd[4 * h + 3]};
-                    Stage::put(tileL, lane, 0, h, t, v);
+                for (int hq = 0; hq < Q; hq++) {
+                    u32x4 v = {pack_lo16(h[8 * hq + 0], h[8 * hq + 1]), pack_lo16(h[8 * hq + 2], h[8 * hq + 3]),
+                               pack_lo16(h[8 * hq + 4], h[8 * hq + 5]), pack_lo16(h[8 * hq + 6], h[8 * hq + 7])};
+                    *reinterpret_cast<u32x4 *>(putPtr + hq * 64 * kStageLine + (K << 4)) = v;
                 }
             }
-            stage.store();
-            stage.fetch(tileL, waveBase, lane, t);
-            stage.fetch_route(tileL, lane, t + 1);
+        }
+        if constexpr (STORE) {
+            flush();
+            constexpr int O = (K + 1) & 7; /* the owners of the lines that are complete now */
+            const uint32_t r = rt[O];
+            const bool valid = (uint32_t)t >= (r & 0xFFFFu) && (uint32_t)t <= (r >> 16);
+            pendN = valid ? (int)nv[O] : 0;
+            pendDst = waveBase + (size_t)t * Stage::kStepElems + (lane << 3);
+#pragma unroll
+            for (int hq = 0; hq < Q; hq++) pend[hq] = *reinterpret_cast<const u32x4 *>(fetchPtr[O] + hq * 64 * kStageLine);
         }
     };
     {
         int t = 0;
-        for (; t + 1 < steps; t += 2) { /* two steps per trip (registers swap roles instead of moving, keys fold with max3) */
-            lane_step(t);
-            lane_step(t + 1);
+        for (; t + 8 <= steps; t += 8) { /* eight steps per trip: every LDS address of the line stage is a register + an immediate */
+            lane_step(t + 0, std::integral_constant<int, 0>{}); lane_step(t + 1, std::integral_constant<int, 1>{});
+            lane_step(t + 2, std::integral_constant<int, 2>{}); lane_step(t + 3, std::integral_constant<int, 3>{});
+            lane_step(t + 4, std::integral_constant<int, 4>{}); lane_step(t + 5, std::integral_constant<int, 5>{});
+            lane_step(t + 6, std::integral_constant<int, 6>{}); lane_step(t + 7, std::integral_constant<int, 7>{});
         }
-        if (t < steps) lane_step(t);
+        if (t + 0 < steps) lane_step(t + 0, std::integral_constant<int, 0>{});
+        if (t + 1 < steps) lane_step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < steps) lane_step(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < steps) lane_step(t + 3, std::integral_constant<int, 3>{});
+        if (t + 4 < steps) lane_step(t + 4, std::integral_constant<int, 4>{});
+        if (t + 5 < steps) lane_step(t + 5, std::integral_constant<int, 5>{});
+        if (t + 6 < steps) lane_step(t + 6, std::integral_constant<int, 6>{});
     }
-    if constexpr (STORE) stage.store();
+    if constexpr (STORE) flush();
     if constexpr (LOCAL) {
         /* first strict maximum in row-major order over the slot's lanes (rows ascend with the lane): the slot's first lane
          * scans its lanes' (score, row, column) in the lane scratch */
         int bestv = 0, bestrow = 0, bestcol = 0;
         lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
         int *mine = reinterpret_cast<int *>(scratch + lane * 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* (the line stage this aliases has been read to the end) */
+        __builtin_amdgcn_wave_barrier();
         mine[0] = bestv; mine[1] = bestrow; mine[2] = bestcol;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the other lanes' entries are read below: keep the order */
         __builtin_amdgcn_wave_barrier();
@@ -682,7 +758,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
             int v = st.Hl[0];
 #pragma unroll
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-            a.score[p] = v; a.endRow[p] = m; a.endCol[p] = n;
+            a.score[p] = v - gap; a.endRow[p] = m; a.endCol[p] = n; /* (the state is H + gap) */
         }
     }
 }

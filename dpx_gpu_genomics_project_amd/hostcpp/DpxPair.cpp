@@ -89,13 +89,17 @@ void runGroup(const std::vector<Request *> &grp, bool wantMatrices, int device) 
 // ~0.2 ms whatever the number of pairs in it, so concurrent callers are combined: a thread that finds a free device
 // becomes a leader, lets the others queue up for a moment, runs everybody's pairs as one device batch and hands the
 // results back.  Same results, same stdout; the per-pair cost drops by about the number of threads.
-// Several devices: up to one leader per visible GPU at a time, devices dealt round-robin -- the unchanged main.cpp then
-// keeps a whole node busy from ONE process (DPX_DEVICES=n limits the devices used; DPX_CLASS_LEADERS=n sets the number
-// of concurrent leaders independently, e.g. to rehearse the multi-device hand-over on a one-GPU box).
+// Several devices: up to one leader per visible GPU at a time, devices dealt round-robin (DPX_DEVICES=n limits the devices
+// used; DPX_CLASS_LEADERS=n sets the number of concurrent leaders independently, e.g. to rehearse the multi-device hand-over
+// on a one-GPU box).  While a leader is gathering nobody else is elected (the arrivals are what it is waiting for); when its
+// window closes it takes only ITS SHARE of the queue -- queue / (free leader slots + 1) requests -- and wakes the others, who
+// lead the rest at once, without a window of their own: 20 callers on 8 devices become groups of 3,3,3,3,2,2,2,2, on one
+// device one group of 20.  (Rehearsed with several leaders on ONE GPU only -- no multi-GPU box was available to the builder.)
 std::mutex g_mu;
 std::condition_variable g_cv;
 std::vector<Request *> g_queue;
 int g_activeLeaders = 0, g_maxLeaders = 0, g_numDevices = 0;
+bool g_gathering = false; // a leader is inside its gather window
 unsigned g_nextSlot = 0;
 
 void initDevices() { // under g_mu
@@ -138,20 +142,29 @@ void dpxAlignPair(int algo, const std::string &reference, const std::string &que
     g_queue.push_back(&rq);
     for (;;) {
         if (rq.done) return;                                          // a leader has served this request
-        if (g_activeLeaders >= g_maxLeaders || g_queue.empty()) {     // no free device, or this request is in a leader's hands
-            g_cv.wait(lk);
+        if (g_activeLeaders >= g_maxLeaders || g_queue.empty() || g_gathering) { // no free device, nothing queued (this request is in
+            g_cv.wait(lk);                                                         // a leader's hands), or a leader is still gathering
             continue;
         }
         g_activeLeaders++; // become a leader on the next device
         const int device = (int)(g_nextSlot++ % (unsigned)g_numDevices);
-        gatherWindow(lk);
-        // serve everything queued with the parameters of the oldest request (usually everything), then retire
+        if (g_queue.size() <= 1) { // alone so far: give the other callers a moment to arrive (a queue somebody left behind is served at once)
+            g_gathering = true;
+            gatherWindow(lk);
+            g_gathering = false;
+        }
+        // this leader's share of the requests that carry the parameters of the oldest one; the rest stays queued for the next leader
         std::vector<Request *> grp, rest;
         if (!g_queue.empty()) {
             const Request &head = *g_queue.front();
-            for (Request *r : g_queue) (r->sameParams(head) ? grp : rest).push_back(r);
+            size_t same = 0;
+            for (Request *r : g_queue) same += r->sameParams(head) ? 1 : 0;
+            const size_t couldRun = (size_t)std::max(1, g_maxLeaders - g_activeLeaders + 1); // this leader + the free slots
+            const size_t share = (same + couldRun - 1) / couldRun;
+            for (Request *r : g_queue) ((r->sameParams(head) && grp.size() < share) ? grp : rest).push_back(r);
             g_queue.swap(rest);
         }
+        if (!g_queue.empty()) g_cv.notify_all(); // somebody else leads the rest, now
         lk.unlock();
         if (!grp.empty()) runGroup(grp, false, device);
         lk.lock();

@@ -8,7 +8,12 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch 10000] [-device 0] [-noprint] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-rank r -world w]
+//
+// Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
+// reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
+// V14.cu:144-213 -- 10000 pairs of 1024 x 1024 would be a 22 GB pool whose allocation costs 50 times the fill).  Two such
+// pools are built on a helper thread while the file is being parsed and then recycled by every batch.
 //
 // Multi-GPU: pairs are independent, so every GPU gets one process with its own contiguous shard of the file:
 // `-rank r -world w` aligns only pairs [ceil(N/w)*r, ceil(N/w)*(r+1)) (the same split as shard.py / bench.py) and
@@ -48,7 +53,8 @@ int main(int argc, char *argv[]) {
     }
     const char *pairFileName = nullptr;
     int match = 3, mismatch = -1, gapOpen = -2, gapExtend = -1, band = 128, device = 0, rank = 0, world = 1;
-    size_t batchSize = 10000; // BATCH_SIZE of the reference's final version (V19.cu:9)
+    size_t batchSize = 0;     // 0: from the pool budget (the reference's BATCH_SIZE, V19.cu:9, assumes short reads)
+    double poolGb = 4.0;
     bool print = true;
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
@@ -64,13 +70,15 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-algo")) algoName = next("-algo");
         else if (!strcmp(argv[i], "-band")) band = atoi(next("-band"));
         else if (!strcmp(argv[i], "-batch")) batchSize = (size_t)atoll(next("-batch"));
+        else if (!strcmp(argv[i], "-pool-gb")) poolGb = atof(next("-pool-gb"));
         else if (!strcmp(argv[i], "-device")) device = atoi(next("-device"));
         else if (!strcmp(argv[i], "-noprint")) print = false;
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
     }
-    if (!pairFileName || batchSize == 0) { fprintf(stderr, "need -pairs <file>\n"); exit(EXIT_FAILURE); }
+    if (!pairFileName) { fprintf(stderr, "need -pairs <file>\n"); exit(EXIT_FAILURE); }
+    if (poolGb < 0.0625 || poolGb > 200) { fprintf(stderr, "bad -pool-gb\n"); exit(EXIT_FAILURE); }
     if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "bad -rank/-world\n"); exit(EXIT_FAILURE); }
     const int algo = algoName == "LNW" ? DPX_ALGO_LNW : algoName == "LSW" ? DPX_ALGO_LSW : algoName == "ANW" ? DPX_ALGO_ANW
                      : algoName == "BSW" ? DPX_ALGO_BSW : -1;
@@ -88,6 +96,13 @@ int main(int argc, char *argv[]) {
     if ((rc = dpx_device_info(name, sizeof name, &cus, &hbm)) != DPX_OK) die("FAILED TO GET DEVICE PROPERTIES", rc);
     printf("Device %d is%s with %d compute units, %.0f GB.\n\n", device, name, cus, (double)hbm / 1e9);
 
+    // the two matrix pools of the pipeline are built while the file is parsed (nothing else needs the device yet)
+    // (the budget is per score plane: the three planes of the affine algorithm get three times the bytes, so that a batch holds
+    // as many pairs -- and fills the chip as well -- as a linear-gap batch of the same shapes)
+    const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
+    std::thread reserve;
+    if (batchSize == 0) reserve = std::thread([poolBudget]() { (void)dpx_pool_reserve(poolBudget, 2); });
+
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;
     char *sequences;
@@ -100,6 +115,13 @@ int main(int argc, char *argv[]) {
     const size_t shardLo = 0, shardHi = fileInfo.numPairs; // indices into this rank's own records
     if (world > 1) printf("Rank %d of %d: pairs [%zu, %zu)\n\n", rank, world, shardFirst, shardFirst + fileInfo.numPairs);
 
+    if (batchSize == 0) { // pairs per batch from the pool budget: 2 bytes per cell and plane, rows / columns padded as the layouts pad them
+        const double cols = (algo == DPX_ALGO_BSW && 2.0 * band < (double)fileInfo.maxReferenceLength) ? 2.0 * band + 8 : (double)fileInfo.maxReferenceLength + 128;
+        const double perPair = 2.0 * (algo == DPX_ALGO_ANW ? 3 : 1) * ((double)fileInfo.maxQueryLength + 64) * cols;
+        const double fit = (double)poolBudget / (perPair > 0 ? perPair : 1);
+        batchSize = (size_t)std::min(20000.0, std::max(64.0, fit));
+    }
+    if (reserve.joinable()) reserve.join();
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
     printf("Pair # | Score\n");
@@ -153,11 +175,11 @@ int main(int argc, char *argv[]) {
         if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
         filling = next;
         // Two batches in flight need two matrix pools.  Allocating tens of GB costs hundreds of ms (more than the overlap of one
-        // batch's traceback with the next batch's fill can ever win back), so batches with big pools run one after the other and
-        // share ONE parked pool; the printer thread still overlaps.
+        // batch's traceback with the next batch's fill can ever win back), so batches with pools of 16 GiB or more (an explicit
+        // -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
         uint64_t matrixBytes = 0;
         dpx_batch_info(filling.b, nullptr, nullptr, &matrixBytes, nullptr);
-        if (matrixBytes >= (2ull << 30)) finish(filling);
+        if (matrixBytes >= (16ull << 30)) finish(filling);
     }
     if (filling.b) finish(filling);
     retire_printed();

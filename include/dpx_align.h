@@ -92,6 +92,10 @@ int dpx_device_count(int *count);
 /* name (<=255 chars), CU count, HBM bytes of the bound device; any pointer may be NULL */
 int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBytes);
 int dpx_shutdown(void);
+/* Allocate `count` (1 or 2) matrix pools of `bytes` each on the default device and park them for the batches to come (any batch
+ * whose matrices fit takes a parked pool instead of allocating).  Meant for a helper thread while the caller parses its input:
+ * the reference sizes its device buffers once, before the batch loop (cuda/LNW/LinearNeedlemanWunschV14.cu:144-213). */
+int dpx_pool_reserve(size_t bytes, int count);
 const char *dpx_strerror(int status);
 const char *dpx_last_error(void); /* thread-local text of the last HIP failure */
 int dpx_abi_version(void);

@@ -92,6 +92,26 @@ def test_class_driver_and_batched_driver_match_reference_stdout(algo):
     assert out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time (usec): ")] == golden(algo)
 
 
+def test_batches_from_the_pool_budget_print_the_same_text(tmp_path):
+    """Round 3: without -batch the batched driver sizes its batches from a matrix-pool budget (-pool-gb; two pools are reserved on a
+    helper thread while the file is parsed, dpx_pool_reserve).  100 pairs of 700 x 900 under a 64-MiB budget = 3 batches on two
+    recycled pools: same stdout as one explicit batch, scores as the oracle."""
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    from dpx_gpu_genomics_project_amd.synth import make_batch
+    sb = make_batch(100, 700, 900, seed=31, first_index=90)
+    path = str(tmp_path / "p100.txt")
+    write_pairs_file(sb, path)
+    body = lambda out: out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time (usec): ")]
+    for algo in ("LSW", "ANW"):
+        one = body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo, "-batch", "100"]))
+        auto = body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo, "-pool-gb", "0.0625"]))
+        dflt = body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo]))
+        assert one == auto == dflt
+        if algo == "LSW":
+            for p in (0, 41, 42, 99):
+                assert f"\n{p} | {O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, want_dir=False).score}\n" in "\n" + one
+
+
 def test_tail_pairs_are_not_dropped(tmp_path):
     """The reference main drops pairs past the last full 400 (c++/main.cpp:169); the mirror's drivers must not."""
     subprocess.run(["make", "-s", "-C", HOST], check=True)

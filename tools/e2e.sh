@@ -4,7 +4,7 @@
 set -e
 N=${1:-10000}
 SHAPE=${2:-long}
-BATCH=5000; [ $SHAPE = short ] && BATCH=${3:-20000}
+BATCHARG=""; [ -n "${3:-}" ] && BATCHARG="-batch $3"   # default: dpx_main sizes its batches from its pool budget (-pool-gb 4)
 python - <<PY
 import sys; sys.path.insert(0, ".")
 import dpx_gpu_genomics_project_amd as dpx
@@ -16,7 +16,7 @@ make -s -C dpx_gpu_genomics_project_amd/hostcpp
 for algo in LSW LNW ANW; do
   EXT=""; OPEN=-2; [ $algo = ANW ] && EXT="-extend -1" && OPEN=-3
   echo "== $algo $N pairs ($SHAPE), print to file"
-  dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT -batch $BATCH > /tmp/e2e_out.txt
+  dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT $BATCHARG ${E2E_EXTRA:-} > /tmp/e2e_out.txt
   grep -E "^Elapsed|^Kernel|^Memory|^Backtracking|^Printing|^GCUPS" /tmp/e2e_out.txt | tr '\n' ' '; echo
   ls -la /tmp/e2e_out.txt | awk '{print "output bytes", $5}'
 done
