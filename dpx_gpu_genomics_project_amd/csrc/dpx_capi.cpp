@@ -960,7 +960,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 32; b->pairs[i].rows = (uint16_t)sR; }
             /* packed split kernel (round 3): couples of equal-shaped pairs, two per workgroup on the VOP3P pipe -- half the vector
              * instructions per cell of a kernel that is bound by its instruction stream.  Needs the 16-bit wrapping adds to be safe
-             * (packed_safe) and, for SW, (score * R + R-1) to fit 16 bits (the row-tag keys).  DPX_SPLIT_PK=0/1 overrides. */
+             * (packed_safe) and, for SW, (score * R + R-1) to fit 16 bits (the row-tag keys). */
             dpx_params kp = *params;
             kp.algo = kernelAlgo;
             auto pos = [](long long v) { return v > 0 ? v : 0; };
@@ -970,7 +970,10 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             const size_t ldsPk = 1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgePk * 4;
             bool splitPk = numPairs >= 2 && packed_safe(kp, b->maxM, b->maxN) && (kernelAlgo != DPX_ALGO_LSW || top * sR + sR - 1 <= 65535) &&
                            ldsPk <= 160u * 1024u;
+            /* measured (profiles/r03): 1000 x 512^2 0.170 vs 0.118 ms, 500 x 1024^2 +5 %, 2000 / 3000 x 1024^2 -1 % / -3 %: with about one
+             * wave per SIMD the fill is bound by the latency of a step, and a packed step is longer -- opt-in (DPX_SPLIT_PK=1) */
             if (const char *env = getenv("DPX_SPLIT_PK")) splitPk = splitPk && atoi(env) != 0;
+            else splitPk = false;
             if (splitPk) {
                 std::vector<int32_t> idx(numPairs);
                 std::iota(idx.begin(), idx.end(), 0);

@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
     if (a.order) p = a.order[p];
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m; /* host guarantees m > 0, n > 0 */
-    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    const int gap = a.gapOpen, matchG = a.match - gap, mismatchG = a.mismatch - gap; /* the state is H + gap (lin_cells_g) */
     const int W = dpx_tiled_stripes(m, R);
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
@@ -973,10 +973,10 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
     load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+        st.Hl[r] = (LOCAL ? 0 : (row0 + 1 + r) * gap) + gap;
         st.key[r] = 0u;
     }
-    st.dtop = LOCAL ? 0 : row0 * gap;
+    st.dtop = (LOCAL ? 0 : row0 * gap) + gap;
     const bool hasNext = w + 1 < W;
     const int rowsHere = min(m - w * 64 * R, 64 * R);
     const int storeLanes = min(64, (((rowsHere + R - 1) / R) + 7) & ~7); /* row-owning lanes, rounded up to whole 128-byte lines */
@@ -991,6 +991,9 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
      * edge write costs one ds_write_b16 per step and no exec juggling */
     int16_t *dump = reinterpret_cast<int16_t *>(smem + 384) + 16 * 0;
     uint32_t acc[4];
+    int hv[R]; /* the plain scores of the lane's last column (outside the ramps every lane has one every step) */
+#pragma unroll
+    for (int r = 0; r < R; r++) hv[r] = st.Hl[r] - gap;
     /* one block of 16 steps; MASKED: the skew ramps, where a lane may be before column 1 or past column n */
     auto block16 = [&](const int tb, auto maskedTag) {
         constexpr bool MASKED = decltype(maskedTag)::value;
@@ -999,31 +1002,32 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
         const unsigned char *rpb = rp + tb;
         const int16_t *epb = edgePrev + tb;
         int rcN = rpb[0];
-        int e0N = (w == 0) ? (LOCAL ? 0 : (tb + 1) * gap) : (int)epb[1];
+        int e0N = ((w == 0) ? (LOCAL ? 0 : (tb + 1) * gap) : (int)epb[1]) + gap; /* "up" of lane 0, + gap like every state value */
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int t = tb + g;
             const int rc = rcN, e0 = e0N;
             rcN = rpb[g + 1];
-            e0N = (w == 0) ? (LOCAL ? 0 : (t + 2) * gap) : (int)epb[g + 2]; /* (entries past n are never used) */
+            e0N = ((w == 0) ? (LOCAL ? 0 : (t + 2) * gap) : (int)epb[g + 2]) + gap; /* (entries past n are never used) */
             const int upin = wave_shr1(st.Hl[R - 1], e0);
             const int j = t - lane + 1;
+            const unsigned negj = 0xFFFFu - (unsigned)j;
             if constexpr (MASKED) {
                 if (j >= 1 && j <= n) {
-                    lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
-                    if (hasNext && lane == 63) edgeMine[j] = (int16_t)st.Hl[R - 1];
+                    lin_cells_g<R, LOCAL>(st, upin, rc, negj, matchG, mismatchG, gap, hv);
+                    if (hasNext && lane == 63) edgeMine[j] = (int16_t)hv[R - 1];
                 }
             } else {
-                lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
-                ew[g] = (int16_t)st.Hl[R - 1];
+                lin_cells_g<R, LOCAL>(st, upin, rc, negj, matchG, mismatchG, gap, hv);
+                ew[g] = (int16_t)hv[R - 1];
             }
             if constexpr (R == 8) {
-                acc[0] = pack_lo16(st.Hl[0], st.Hl[1]); acc[1] = pack_lo16(st.Hl[2], st.Hl[3]);
-                acc[2] = pack_lo16(st.Hl[4], st.Hl[5]); acc[3] = pack_lo16(st.Hl[6], st.Hl[7]);
+                acc[0] = pack_lo16(hv[0], hv[1]); acc[1] = pack_lo16(hv[2], hv[3]);
+                acc[2] = pack_lo16(hv[4], hv[5]); acc[3] = pack_lo16(hv[6], hv[7]);
             } else if constexpr (R == 4) {
-                acc[2 * (g % G)] = pack_lo16(st.Hl[0], st.Hl[1]); acc[2 * (g % G) + 1] = pack_lo16(st.Hl[2], st.Hl[3]);
+                acc[2 * (g % G)] = pack_lo16(hv[0], hv[1]); acc[2 * (g % G) + 1] = pack_lo16(hv[2], hv[3]);
             } else {
-                acc[g % G] = pack_lo16(st.Hl[0], st.Hl[1]);
+                acc[g % G] = pack_lo16(hv[0], hv[1]);
             }
             if ((g % G) == G - 1 && t - (G - 1) < n + 63) { /* whole lines, also on the skew ramps (see lin_step); nothing past the last step */
                 /* (no ramp_stores() here: this kernel runs small batches, which are bound by the latency of a step, not by bytes --
@@ -1062,7 +1066,7 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split(const
             int v = st.Hl[0];
 #pragma unroll
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-            a.score[p] = v; a.endRow[p] = m; a.endCol[p] = n;
+            a.score[p] = v - gap; a.endRow[p] = m; a.endCol[p] = n; /* (the state is H + gap) */
         }
     }
     if constexpr (LOCAL) {

@@ -156,3 +156,32 @@ def test_packed_is_refused_where_16_bit_adds_would_wrap(gpu, monkeypatch):
     with pytest.raises(gpu.DpxError) as e:
         gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, 3, -(1 << 21), -2)
     assert e.value.status == -4
+
+
+def test_row_tag_keys_and_their_limit(gpu, monkeypatch):
+    """Round 3: the packed SW kernel tracks ONE (score * R + R-1 - row, column) key per pair and lane where that fits 16 bits, the
+    round-2 per-row keys otherwise; DPX_ROW_TAGS=0 forces the per-row keys.  Same start cells either way, at the limit too."""
+    monkeypatch.setenv("DPX_PACKED", "1")
+    rng = np.random.default_rng(31)
+    acgt = np.array([48, 49, 50, 51], np.uint8)
+    ref = rng.choice(acgt, size=1023).astype(np.uint8).tobytes()
+    cases = [
+        (from_strings([(ref, ref), (ref, ref[::-1])] + [(b"0" * 1023, b"0" * 1023)] * 2), (4, -1, -2), 1),    # 4092 * 16 + 15 = 65487: tags
+        (from_strings([(ref + b"0", ref + b"0"), (ref + b"1", ref[::-1] + b"1")]), (4, -1, -2), 0),          # 4096 * 16 + 15 > 65535: per-row keys
+        (_uniform(rng, 6, 1000, 900, acgt), (3, -1, -2), 1),
+        (_uniform(rng, 6, 700, 900, acgt), (3, 5, 4), 0),              # positive gap: the score bound (9900 * 16) leaves the tag range
+        (_uniform(rng, 6, 77, 1500, np.array([0, 255], np.uint8)), (1, 0, 0), 1),   # many equal scores: smallest row, then smallest column
+    ]
+    for sb, w, want_tags in cases:
+        with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *w) as b:
+            d = b.describe()
+            assert d["kernel"] == "k_linear_fill_pk" and d["row_tags"] == want_tags, (w, d)
+            b.fill()
+            tagged = [x.copy() for x in b.results()]
+        _check(gpu, "LSW", sb, w, every=3)
+        monkeypatch.setenv("DPX_ROW_TAGS", "0")
+        with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *w) as b:
+            assert b.describe()["row_tags"] == 0
+            b.fill()
+            assert all(np.array_equal(x, y) for x, y in zip(tagged, b.results()))
+        monkeypatch.delenv("DPX_ROW_TAGS")

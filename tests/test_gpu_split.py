@@ -13,8 +13,7 @@ pytestmark = pytest.mark.gpu
 def split_kernel(request, monkeypatch):
     """Round 3: equal-shaped pairs of a split batch run two per workgroup on the packed-int16 pipe (k_linear_split_pk), leftovers
     and batches whose weights the 16-bit pipe cannot take on the int32 kernel (k_linear_split).  DPX_SPLIT_PK=0: int32 only."""
-    if request.param == "int32-only":
-        monkeypatch.setenv("DPX_SPLIT_PK", "0")
+    monkeypatch.setenv("DPX_SPLIT_PK", "0" if request.param == "int32-only" else "1")  # (the packed kernel is opt-in: it loses at ~1 wave per SIMD)
     return request.param
 
 
