@@ -365,6 +365,7 @@ struct dpx_batch {
     size_t streamLds = 0;
     bool packed = false;
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
+    bool lanesPk = false;  /* lane-packed batch on k_linear_lanes_pk (two row blocks of a pair in the halves of every register) */
     bool splitPk = false;  /* ... two equal-shaped pairs per workgroup on the packed-int16 pipe (k_linear_split_pk); leftovers on k_linear_split */
     size_t splitPkLds = 0;
     int splitWaves = 0;
@@ -556,9 +557,10 @@ static int lanes_rows(int maxM, int algo) { return (maxM <= 512 || algo == DPX_A
  * LDS reference area.  Best fit over a window of open waves, so that the pairs of a wave have nearly the same reference
  * length (the wave runs max(n + lanes) steps) and the lanes fill up: 100k short reads (queries 80-130) reach 94 % lane
  * occupancy.  Returns the reference area in bytes; `idx` comes back in slot order (= matrix placement order). */
-static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int32_t> &idx, int R, int maxN, std::vector<dpx_wave_desc> &waves) {
+static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int32_t> &idx, int R, int maxN, size_t refFloor, int maxSlots,
+                         std::vector<dpx_wave_desc> &waves) {
     struct Bin { dpx_wave_desc d; int lanes = 0, slots = 0; size_t ref = 0; bool closed = false; };
-    const size_t refCap = std::max<size_t>(1024, align_up((size_t)maxN + 31, 16));
+    const size_t refCap = std::max<size_t>(refFloor, align_up((size_t)maxN + 31, 16)); /* bytes of staged references per wave */
     constexpr size_t kWindow = 256; /* open waves: pairs arrive sorted by reference length, so a window keeps a wave's pairs alike */
     std::vector<Bin> bins;          /* in opening order = emission order */
     std::vector<int32_t> byFree[65]; /* open bins by free lanes (entries go stale when a bin moves on: checked on use) */
@@ -575,7 +577,7 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
                 const int32_t k = lst.back();
                 const Bin &bn = bins[k];
                 if (bn.closed || 64 - bn.lanes != f) { lst.pop_back(); continue; } /* stale entry */
-                if (bn.slots >= DPX_WAVE_SLOTS || bn.ref + need > refCap) break;   /* this bucket's newest bin is full in another way */
+                if (bn.slots >= maxSlots || bn.ref + need > refCap) break;   /* this bucket's newest bin is full in another way */
                 best = k;
                 lst.pop_back();
                 break;
@@ -600,7 +602,7 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
         bn.lanes += L;
         bn.slots++;
         bn.ref += need;
-        if (bn.lanes < 64 && bn.slots < DPX_WAVE_SLOTS) byFree[64 - bn.lanes].push_back(best);
+        if (bn.lanes < 64 && bn.slots < maxSlots) byFree[64 - bn.lanes].push_back(best);
         else { bn.closed = true; numOpen--; }
     }
     std::vector<int32_t> order;
@@ -843,7 +845,25 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     const bool linearAlgo = kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW;
     const bool lanesAlgo = linearAlgo || kernelAlgo == DPX_ALGO_ANW;
     /* (the staged references of a wave's pairs share its LDS: keep the path to references that leave the request small) */
-    const int kLanesR = lanes_rows(b->maxM, kernelAlgo);
+    /* Packed lane kernel (round 3, k_linear_lanes_pk): 16 rows per lane as two 8-row blocks of the SAME pair in the two halves of every
+     * register.  Needs the 16-bit wrapping adds to be safe (packed_safe), room below the smallest border for its "minus infinity"
+     * (the low half's column 0), and for SW: score * 8 + 7 in 16 bits (row tags) and gap <= 0, mismatch <= 0 (rows past the query's
+     * end are not masked: with such weights they never exceed the real rows above them).  DPX_LANES_PK=0 keeps the int32 kernels. */
+    bool lanesPk = false;
+    if (linearAlgo && b->store && b->maxM > 0 && b->maxM <= 1024) {
+        dpx_params kp = *params;
+        kp.algo = kernelAlgo;
+        auto pos = [](long long v) { return v > 0 ? v : 0; };
+        const long long wmin = std::min<long long>({params->match, params->mismatch, params->gapOpen, 0});
+        const long long wmax = std::max<long long>({params->match, params->mismatch, params->gapOpen, 0});
+        const long long lowest = kernelAlgo == DPX_ALGO_LNW ? std::min<long long>(params->gapOpen, 0) * ((long long)b->maxM + b->maxN) : 0;
+        const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
+                              pos(params->gapOpen) * ((long long)b->maxM + b->maxN);
+        lanesPk = packed_safe(kp, b->maxM, b->maxN) && (-32768 - wmin + wmax <= lowest) &&
+                  (kernelAlgo != DPX_ALGO_LSW || (top * 8 + 7 <= 65535 && params->gapOpen <= 0 && params->mismatch <= 0));
+        if (const char *env = getenv("DPX_LANES_PK")) lanesPk = lanesPk && atoi(env) != 0;
+    }
+    const int kLanesR = lanesPk ? 16 : lanes_rows(b->maxM, kernelAlgo);
     const bool lanesShape = lanesAlgo && b->maxM <= 64 * kLanesR && b->maxM > 0 && b->maxN <= 4096;
     /* measured (tools/lanes_threshold.py): short reads x2048 56 vs 66 us, x4096 56 vs 114, x16384 121 vs 222 (below 2048 pairs the
      * split / one-wave-per-pair kernels win); 20000 x 250x300 (32 lanes per pair, two per wave) 608 vs 645 us, but 300x300 (38 lanes, one
@@ -877,11 +897,14 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         lanesPairs = couples.size();
         b->lanePacked = !couples.empty();
         if (b->lanePacked) {
-            lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, waves); /* `couples` comes back in slot order */
+            /* (reference area: 1 KiB keeps four workgroups of the 8-rows-per-lane kernels on a CU, up to 8 pairs per wave as in round 2; the
+             * packed kernel's pairs take half the lanes, so its waves hold up to 12 pairs in 2 KiB: 2 x (18 + 2) KiB x 4 waves = 160 KiB) */
+            lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, lanesPk ? 2048 : 1024, lanesPk ? DPX_WAVE_SLOTS : 8, waves); /* `couples` comes back in slot order */
             size_t lanesUsed = 0;
             for (const dpx_wave_desc &wd : waves) for (int k = 0; k < DPX_WAVE_SLOTS; k++) lanesUsed += wd.num[k];
             if (!lanesForced && lanesUsed * 100 < waves.size() * 64 * 85) b->lanePacked = false; /* under 85 % of the lanes own rows: not worth it */
         }
+        b->lanesPk = b->lanePacked && lanesPk;
         if (!b->lanePacked) { /* back to the other kernels */
             b->R = R;
             singles.clear();
@@ -1334,7 +1357,8 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     /* secondary kernel first (it is the short one; the main kernel then fills the chip around it) */
     if (b->lanePacked) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side); /* empty pairs */
-        if (e == hipSuccess) e = dpx_launch_fill_lanes(b->pkArgs, b->kernelAlgo, b->R, b->store, b->pkLdsBytes, s);
+        if (e == hipSuccess) e = b->lanesPk ? dpx_launch_fill_lanes_packed(b->pkArgs, b->kernelAlgo, b->pkLdsBytes, s)
+                                            : dpx_launch_fill_lanes(b->pkArgs, b->kernelAlgo, b->R, b->store, b->pkLdsBytes, s);
     } else if (b->packed) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
         if (e == hipSuccess) e = b->kernelAlgo == DPX_ALGO_BSW ? dpx_launch_banded_packed(b->pkArgs, b->R, b->pkLdsBytes, s)
@@ -1633,10 +1657,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+                         : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d",
-                       names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
+                       names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
                        b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags);
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;

@@ -46,6 +46,7 @@ hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool s
  * waves per workgroup of the kernel for `algo` */
 size_t dpx_lanes_stage_bytes(int algo, int R, bool store);
 int dpx_lanes_waves_per_block(int algo);
+hipError_t dpx_launch_fill_lanes_packed(const dpx_fill_args &a, int algo, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);

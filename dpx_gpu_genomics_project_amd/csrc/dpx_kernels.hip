@@ -566,11 +566,13 @@ struct LaneSlot {
 };
 __device__ __forceinline__ LaneSlot find_slot(const dpx_wave_desc *wd, const int lane) {
     LaneSlot s{false, 0, 0, 0, 0, 0u};
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(wd); /* wave-uniform address: 16 dwords through scalar loads */
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(wd); /* wave-uniform address: 2 dwords per slot through scalar loads */
+    static_assert(DPX_WAVE_SLOTS % 4 == 0 && sizeof(dpx_wave_desc) == 8 * DPX_WAVE_SLOTS, "descriptor is read as dwords");
+    constexpr int kFirst = DPX_WAVE_SLOTS, kNum = DPX_WAVE_SLOTS + DPX_WAVE_SLOTS / 4, kRef = DPX_WAVE_SLOTS + DPX_WAVE_SLOTS / 2; /* dword offsets */
 #pragma unroll
     for (int k = 0; k < DPX_WAVE_SLOTS; k++) {
-        const int f = (int)((w[8 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu), c = (int)((w[10 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu);
-        const uint32_t ro = (w[12 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
+        const int f = (int)((w[kFirst + (k >> 2)] >> (8 * (k & 3))) & 0xFFu), c = (int)((w[kNum + (k >> 2)] >> (8 * (k & 3))) & 0xFFu);
+        const uint32_t ro = (w[kRef + (k >> 1)] >> (16 * (k & 1))) & 0xFFFFu;
         if (lane >= f && lane < f + c) { s.has = true; s.p = (int)w[k]; s.l = lane - f; s.num = c; s.d = f & 7; s.refOff = ro << 4; }
     }
     return s;
@@ -1340,6 +1342,221 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS, DPX_PK_MIN_BLOCKS) k_linear_
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
             a.score[pA] = (int)(int16_t)(v >> 16); a.endRow[pA] = m; a.endCol[pA] = n;
             a.score[pB] = (int)(int16_t)(v & 0xFFFFu); a.endRow[pB] = m; a.endCol[pB] = n;
+        }
+    }
+}
+
+/* =====================================================================================================
+ * Packed lane kernel for short and medium queries (round 3): k_linear_lanes' schedule and tile layout with the packed-int16
+ * arithmetic of k_linear_fill_pk -- but the two halves of a register do not hold two PAIRS (which would need equal shapes), they
+ * hold two ROW BLOCKS OF THE SAME PAIR: a lane owns 16 consecutive rows, rows 0-7 in the high halves and rows 8-15 in the low
+ * halves, and the low half runs ONE COLUMN BEHIND the high half.  A physical lane is two virtual lanes of the wavefront (2l and
+ * 2l+1): the low half takes its "row above" from the lane's own high half of the previous step, the high half from the previous
+ * lane's low half (one DPP move + one v_perm_b32), the diagonal is last step's "row above" as everywhere.  Any mix of shapes
+ * packs as before (a pair of m rows takes ceil(m/16) lanes); the cell update costs 7 (NW) / 8 (SW) VOP3P instructions per TWO
+ * cells instead of 5-6 per cell, and the per-step bookkeeping is shared by 16 rows: the int32 kernel needs 117 vector
+ * instructions per step and 16 rows (2 x 58.5), this one 80.
+ *   - Column 0 of the low half (its first step) needs no mask: its state starts at a large negative value, so that
+ *     max(up+gap, left+gap, diag+s) = up+gap = the column-0 border (SW: 0) -- the host checks that the value cannot wrap.
+ *   - The high half's extra step at column n+1 (while the low half finishes column n) runs only in lanes that own more than
+ *     8 rows; its results are garbage that nothing reads (SW: masked out of the start-cell key).
+ *   - SW start cell: one (H * 8 + 7 - r, column) key per half (pk_row_tag); rows past the query's end are not masked -- the host
+ *     uses this kernel for SW only if gap <= 0 and mismatch <= 0, where such a row can never exceed the real rows above it.
+ *   - Matrices: the SAME tile layout as k_linear_lanes<16> (dpx_layout.h, lanes == 16, rows == 16).  A line's address is a
+ *     function of (row block, column block) only; this kernel just completes the lines in another order: the line of lane
+ *     lambda, block h, that k_linear_lanes<16> writes to chunk T of the wave's stream is complete here in step T + delta + h
+ *     (delta = this schedule's skew minus that one's), so two 8-line stores per step go to per-owner chunks instead of one
+ *     contiguous 2 KiB.  Export and traceback do not know which kernel filled a pair.
+ * ===================================================================================================== */
+template <bool LOCAL>
+__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_fill_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStageBytes = 2 * 64 * kStageLine; /* [block][lane] lines */
+    constexpr int kStepElems = 1024;                 /* int16 elements of one chunk of the wave's stream (two 1-KiB halves) */
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    if (w >= a.numPairs) return;
+    const LaneSlot sl = find_slot(a.waves + w, lane);
+    const bool has = sl.has;
+    const int p = sl.p, l = sl.l;
+    const dpx_pair_dev pr = a.pairs[p];
+    const int n = has ? pr.n : 0, m = has ? pr.m : 0;
+    const int gap = a.gapOpen;
+    const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
+    const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
+    const uint32_t gapP = ((uint32_t)(uint16_t)gap << 16) | (uint16_t)gap;
+    const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
+    const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+
+    unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave; /* [line stage][staged references] */
+    unsigned char *scratch = tileL;
+    unsigned char *refl = tileL + kStageBytes + sl.refOff;
+    const unsigned char *refs = stage_bytes(refl, ref, n, l, max(sl.num, 1));
+
+    const int row0 = l * 16;
+    const int nrows = min(max(m - row0, 0), 16);
+    /* the smallest value that one more weight cannot wrap: "minus infinity" left of column 0 in the low halves */
+    const int wmin = min(min(a.match, a.mismatch), min(gap, 0));
+    const uint32_t negInf = (uint16_t)(-32768 - wmin);
+    uint32_t Hl[8], qc[8], dtop, keyHi = 0u, keyLo = 0u;
+    {
+        int qa[16];
+        load_query_rows<16>(qa, qry, row0, nrows);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            qc[r] = ((uint32_t)qa[r] << 16) | (uint32_t)qa[8 + r]; /* rows past the end: 0x0100, matches no byte */
+            const uint16_t b = (uint16_t)(LOCAL ? 0 : (row0 + 1 + r) * gap);
+            Hl[r] = ((uint32_t)b << 16) | negInf; /* high half: column 0 of its rows; low half: not started */
+        }
+        const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap);
+        dtop = ((uint32_t)b << 16) | negInf;
+    }
+    const int first = lane - l;
+    const int dOld = first & 7, dNew = (2 * first) & 7;
+    const int skew = 2 * l + dNew; /* the HIGH half runs column j = t - skew + 1 in step t, the low half column j - 1 */
+    const int n8 = (n + 7) & ~7;
+    const int LB = (int)dpx_tile8_row_blocks(m);
+    const int nBlocks = has ? min(max(LB - 2 * l, 0), 2) : 0; /* row blocks of this lane that hold rows */
+    /* routing, once: [first | last << 16] completing step of the high block, the same of the low block (one step later), and
+     * delta = how many steps later than in k_linear_lanes<16>'s schedule this lane's lines are complete */
+    {
+        uint32_t *mine = reinterpret_cast<uint32_t *>(tileL + lane * kStageLine + 128);
+        mine[0] = nBlocks >= 1 ? ((uint32_t)(skew + 7) | ((uint32_t)(n8 + skew - 1) << 16)) : 0x00007FFFu; /* (never valid: first > last) */
+        mine[1] = nBlocks >= 2 ? ((uint32_t)(skew + 8) | ((uint32_t)(n8 + skew) << 16)) : 0x00007FFFu;
+        mine[2] = (uint32_t)(skew - (l + dOld));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t rtHi[8], rtLo[8];
+    int dl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t *o = reinterpret_cast<const uint32_t *>(tileL + ((lane & ~7) | k) * kStageLine + 128);
+        rtHi[k] = o[0]; rtLo[k] = o[1]; dl[k] = (int)o[2];
+    }
+    int16_t *waveBase = a.mat + (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff & 0xFFFFFFFFull)));
+    const int lastStep = has ? (nBlocks >= 2 ? n8 + skew : n8 + skew - 1) : -1; /* the step in which this lane's last line is complete */
+    const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(lastStep)) + 1;
+    const unsigned char *rp = refs - skew; /* rp[t] = reference character of the high half's column */
+    const unsigned nEff = nrows > 8 ? (unsigned)n + 1u : (nrows > 0 ? (unsigned)n : 0u); /* on a cell iff (unsigned)(t - skew) < nEff */
+    unsigned char *putPtr = tileL + lane * kStageLine;
+    const unsigned char *fetchPtr[8]; /* piece lane % 8 of the high-block line of lane k of this lane's group (low block: + 64 lines) */
+#pragma unroll
+    for (int k = 0; k < 8; k++) fetchPtr[k] = tileL + ((lane & ~7) | k) * kStageLine + (((lane + 2 * k) & 7) << 4);
+    const int laneElems = ((lane >> 3) << 6) + ((lane & 7) << 3); /* this lane's 16 bytes inside a 1-KiB half chunk */
+    u32x4 pendA, pendB;
+    bool okA = false, okB = false;
+    int16_t *dstA = nullptr, *dstB = nullptr;
+    uint32_t bord = (uint16_t)(-skew * gap); /* NW, first lane of a slot: H[0][j] of the high half's column, j = t - skew + 1 (16 bits; + gap before use) */
+    uint32_t rcCur = rp[0], rcPrev = 0u;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (okA) stream_store(reinterpret_cast<u32x4 *>(dstA), pendA);
+        if (okB) stream_store(reinterpret_cast<u32x4 *>(dstB), pendB);
+    };
+    auto lane_step = [&](const int t, auto kTag) __attribute__((always_inline)) {
+        constexpr int K = decltype(kTag)::value; /* t & 7 */
+        const int tms = t - skew;
+        const uint32_t rcP = (rcCur << 16) | rcPrev; /* {character of column j, of column j-1} */
+        rcPrev = rcCur;
+        rcCur = rp[t + 1];
+        const uint32_t sh = (uint32_t)wave_shr1((int)Hl[7], 0);
+        uint32_t upin = __builtin_amdgcn_perm(sh, Hl[7], 0x05040302u); /* {previous lane's low half, this lane's high half} */
+        if constexpr (!LOCAL) bord = (uint32_t)(uint16_t)(bord + (uint32_t)gap);
+        if (l == 0) upin = (LOCAL ? 0u : (bord << 16)) | (upin & 0xFFFFu); /* a slot's first lane: the row-0 border */
+        if ((unsigned)tms < nEff) {
+            uint32_t u = upin, colMax = 0u;
+            const uint32_t onesP = 0x00010001u;
+            uint32_t dsum[8]; /* diagonal terms first, then every row in place (no register rotation across the masked region, see lin_cells) */
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t differs = dpx::pk_min_u16_raw(qc[r] ^ rcP, onesP);
+                const uint32_t sc = dpx::pk_mad_i16_raw(differs, negDeltaP, matchP);
+                dsum[r] = as_u32((s16x2)(as_s16x2(r == 0 ? dtop : Hl[r - 1]) + as_s16x2(sc)));
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(Hl[r])) + as_s16x2(gapP);
+                s16x2 h = dpx::pk_max(g, as_s16x2(dsum[r]));
+                if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+                u = as_u32(h);
+                Hl[r] = u;
+                if constexpr (LOCAL) {
+                    const uint32_t tg = pk_row_tag_of<8>(u, r);
+                    colMax = r == 0 ? tg : dpx::pk_max_u16_raw(colMax, tg);
+                }
+            }
+            dtop = upin;
+            if constexpr (LOCAL) {
+                const uint32_t negj = 0xFFFEu - (uint32_t)tms;                 /* 0xFFFF - j of the high half */
+                if (tms < n) keyHi = max(keyHi, (colMax & 0xFFFF0000u) | negj); /* (column n+1 does not exist) */
+                keyLo = max(keyLo, (colMax << 16) | (negj + 1u));              /* the low half is on column j - 1 (column 0 scores 0) */
+            }
+            /* park both blocks' 16 bytes in their lines: the high block's column in slot t % 8, the low block's in slot (t-1) % 8 */
+            u32x4 vh = {pk_hi16(Hl[0], Hl[1]), pk_hi16(Hl[2], Hl[3]), pk_hi16(Hl[4], Hl[5]), pk_hi16(Hl[6], Hl[7])};
+            u32x4 vl = {pack_lo16((int)Hl[0], (int)Hl[1]), pack_lo16((int)Hl[2], (int)Hl[3]), pack_lo16((int)Hl[4], (int)Hl[5]), pack_lo16((int)Hl[6], (int)Hl[7])};
+            *reinterpret_cast<u32x4 *>(putPtr + (K << 4)) = vh;
+            *reinterpret_cast<u32x4 *>(putPtr + 64 * kStageLine + (((K + 7) & 7) << 4)) = vl;
+        }
+        flush();
+        /* lines that are complete now: odd steps the HIGH blocks of the lanes (t+1)/2 mod 4 (and + 4) of every group, even steps the
+         * LOW blocks of the lanes t/2 mod 4 (and + 4) */
+        constexpr int H = (K & 1) ? 0 : 1;
+        constexpr int OA = (K & 1) ? (((K + 1) >> 1) & 3) : (K >> 1), OB = OA + 4;
+        const uint32_t ra = H ? rtLo[OA] : rtHi[OA], rb = H ? rtLo[OB] : rtHi[OB];
+        okA = (uint32_t)t >= (ra & 0xFFFFu) && (uint32_t)t <= (ra >> 16);
+        okB = (uint32_t)t >= (rb & 0xFFFFu) && (uint32_t)t <= (rb >> 16);
+        dstA = waveBase + (ptrdiff_t)(t - dl[OA] - H) * kStepElems + (H * 512 + laneElems);
+        dstB = waveBase + (ptrdiff_t)(t - dl[OB] - H) * kStepElems + (H * 512 + laneElems);
+        pendA = *reinterpret_cast<const u32x4 *>(fetchPtr[OA] + H * 64 * kStageLine);
+        pendB = *reinterpret_cast<const u32x4 *>(fetchPtr[OB] + H * 64 * kStageLine);
+    };
+    {
+        int t = 0;
+        for (; t + 8 <= steps; t += 8) {
+            lane_step(t + 0, std::integral_constant<int, 0>{}); lane_step(t + 1, std::integral_constant<int, 1>{});
+            lane_step(t + 2, std::integral_constant<int, 2>{}); lane_step(t + 3, std::integral_constant<int, 3>{});
+            lane_step(t + 4, std::integral_constant<int, 4>{}); lane_step(t + 5, std::integral_constant<int, 5>{});
+            lane_step(t + 6, std::integral_constant<int, 6>{}); lane_step(t + 7, std::integral_constant<int, 7>{});
+        }
+        if (t + 0 < steps) lane_step(t + 0, std::integral_constant<int, 0>{});
+        if (t + 1 < steps) lane_step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < steps) lane_step(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < steps) lane_step(t + 3, std::integral_constant<int, 3>{});
+        if (t + 4 < steps) lane_step(t + 4, std::integral_constant<int, 4>{});
+        if (t + 5 < steps) lane_step(t + 5, std::integral_constant<int, 5>{});
+        if (t + 6 < steps) lane_step(t + 6, std::integral_constant<int, 6>{});
+    }
+    flush();
+    if constexpr (LOCAL) {
+        /* the lane's candidate: the high block's rows come first in row-major order, so the low block must be strictly better */
+        int bestv = (int)(keyHi >> 19), bestrow = row0 + 8 - (int)((keyHi >> 16) & 7), bestcol = 0xFFFF - (int)(keyHi & 0xFFFFu);
+        const int vLo = (int)(keyLo >> 19);
+        if (vLo > bestv) { bestv = vLo; bestrow = row0 + 16 - (int)((keyLo >> 16) & 7); bestcol = 0xFFFF - (int)(keyLo & 0xFFFFu); }
+        int *mine = reinterpret_cast<int *>(scratch + lane * 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* (the line stage this aliases has been read to the end) */
+        __builtin_amdgcn_wave_barrier();
+        mine[0] = bestv; mine[1] = bestrow; mine[2] = bestcol;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (has && l == 0) {
+            for (int k = 1; k < sl.num; k++) {
+                const int *o = reinterpret_cast<const int *>(scratch + (lane + k) * 16);
+                if (o[0] > bestv) { bestv = o[0]; bestrow = o[1]; bestcol = o[2]; }
+            }
+            a.score[p] = bestv; a.endRow[p] = bestv > 0 ? bestrow : 0; a.endCol[p] = bestv > 0 ? bestcol : 0;
+        }
+    } else {
+        const int lm = (m - 1) / 16, rr = (m - 1) % 16; /* owner of row m: its registers hold column n after its last step */
+        if (has && l == lm) {
+            uint32_t v = Hl[0];
+#pragma unroll
+            for (int r = 1; r < 8; r++) v = (r == (rr & 7)) ? Hl[r] : v;
+            a.score[p] = (rr < 8) ? (int)(int16_t)(v >> 16) : (int)(int16_t)(v & 0xFFFFu);
+            a.endRow[p] = m; a.endCol[p] = n;
         }
     }
 }
@@ -2936,6 +3153,15 @@ hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool s
     default: return hipErrorInvalidValue;
     }
 #undef DPX_LANES_CASE
+}
+
+/* packed lane kernel (16 rows per lane, two row blocks of one pair in the two halves): a.waves / a.numPairs as dpx_launch_fill_lanes */
+hipError_t dpx_launch_fill_lanes_packed(const dpx_fill_args &a, int algo, size_t ldsBytes, hipStream_t stream) {
+    if (a.numPairs <= 0) return hipSuccess;
+    const int wpb = DPX_FILL_THREADS / 64;
+    dim3 grid((unsigned)((a.numPairs + wpb - 1) / wpb));
+    return algo == DPX_K_LSW ? launch_lanes_kernel(k_linear_lanes_pk<true>, a, grid, DPX_FILL_THREADS, ldsBytes, stream)
+                             : launch_lanes_kernel(k_linear_lanes_pk<false>, a, grid, DPX_FILL_THREADS, ldsBytes, stream);
 }
 
 /* split kernel (small batches): one workgroup of `waves` waves per pair, a.numPairs workgroups */

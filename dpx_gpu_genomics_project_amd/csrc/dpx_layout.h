@@ -55,7 +55,7 @@ typedef struct dpx_pair_dev {
 /* Lane-packed kernels (k_linear_lanes / k_affine_lanes): what one wave aligns.  Up to DPX_WAVE_SLOTS pairs share the 64
  * lanes; slot k owns lanes [first[k], first[k] + num[k]) with num = ceil(m / rows per lane).  Built by the host
  * (dpx_capi.cpp: pack_waves), read through scalar loads. */
-#define DPX_WAVE_SLOTS 8
+#define DPX_WAVE_SLOTS 12 /* (a multiple of 4: the kernels read the descriptor as dwords; 12 pairs of 5 lanes fill a wave of the packed lane kernel) */
 typedef struct dpx_wave_desc {
     int32_t pair[DPX_WAVE_SLOTS];    /* batch index of the slot's pair */
     uint8_t first[DPX_WAVE_SLOTS];   /* first lane */

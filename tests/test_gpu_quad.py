@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(autouse=True, params=["packed-row-blocks", "int32-lanes"])
+def lanes_kernel(request, monkeypatch):
+    """Round 3: where the weights allow it the linear lane-packed batches run on k_linear_lanes_pk (16 rows per lane, two row blocks
+    of one pair in the halves of every register, the low half one column behind); DPX_LANES_PK=0 keeps the int32 kernels.  Every
+    test of this file runs on both."""
+    if request.param == "int32-lanes":
+        monkeypatch.setenv("DPX_LANES_PK", "0")
+    return request.param
+
+
 W3 = {"LSW": (3, -1, -2, -1), "LNW": (3, -1, -2, -1), "ANW": (3, -1, -3, -1)}
 W5 = {"LSW": (5, -2, -3, -1), "LNW": (5, -2, -3, -1), "ANW": (2, -2, 0, -1)}
 ALGOS = ["LSW", "LNW", "ANW"]
@@ -51,7 +61,7 @@ def test_quad_uniform_shapes(gpu, algo, monkeypatch):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
-def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, monkeypatch):
+def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, lanes_kernel, monkeypatch):
     """Lane-packed kernels at their limits: 8 rows per lane up to 512 query rows (64 lanes), 16 rows per lane (two row blocks
     per lane, linear-gap kernels only) up to 1024; mixes where a wave holds one long and several short pairs."""
     monkeypatch.setenv("DPX_QUAD", "1")
@@ -60,7 +70,8 @@ def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, monkeypatch):
         sb = make_batch(3, m, n, seed=900 + i, first_index=95)
         with gpu.Batch({"LNW": 0, "LSW": 1, "ANW": 2}[algo], sb.sequences, sb.pairs, *W3[algo]) as b:
             d = b.describe()
-            assert d["kernel"].endswith("_lanes") and d["rows_per_lane"] == (8 if m <= 512 else 16), d
+            pk = lanes_kernel == "packed-row-blocks" and algo != "ANW"
+            assert d["kernel"].endswith("_lanes_pk" if pk else "_lanes") and d["rows_per_lane"] == (16 if pk or m > 512 else 8), d
         _check(gpu, algo, sb, W3[algo])
     _check(gpu, algo, make_ragged_batch(40, 20, 500, 30, 400, seed=35), W3[algo], every=4)
     if algo != "ANW":
@@ -112,17 +123,41 @@ def test_quad_is_the_default_for_large_short_read_batches(gpu):
                 assert np.array_equal(b.matrix(p).astype(np.int32), o.H)
 
 
-def test_lanes_are_chosen_where_the_packing_fills_the_wave(gpu):
+def test_lanes_are_chosen_where_the_packing_fills_the_wave(gpu, lanes_kernel):
     """>= 2048 pairs of <= 256 rows take the lane-packed kernels when >= 85 % of the lanes end up owning rows."""
-    for sb, want in ((make_ragged_batch(2100, 80, 130, 100, 160, seed=40), True),    # 10-17 lanes per pair: ~94 % of the lanes
-                     (make_batch(2100, 250, 120, seed=41), True),                     # 32 lanes per pair, two per wave
-                     (make_batch(2100, 180, 120, seed=42), False),                    # 23 lanes per pair: two per wave, 72 %
+    pk = lanes_kernel == "packed-row-blocks"   # 16 rows per lane: half the lanes per pair
+    for sb, want in ((make_ragged_batch(2100, 80, 130, 100, 160, seed=40), True),    # 10-17 (5-9) lanes per pair: ~94 % of the lanes
+                     (make_batch(2100, 250, 120, seed=41), True),                     # 32 (16) lanes per pair, two (four) per wave
+                     (make_batch(2100, 180, 120, seed=42), pk),                       # 23 lanes per pair: two per wave, 72 % (12 lanes: five per wave, 94 %)
                      (make_ragged_batch(2000, 80, 130, 100, 160, seed=43), False)):   # too few pairs
         with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, 3, -1, -2) as b:
             d = b.describe()
-            assert (d["kernel"] == "k_linear_lanes") == want, d
+            assert (d["kernel"] == ("k_linear_lanes_pk" if pk else "k_linear_lanes")) == want, d
             b.fill()
             sc, _, _ = b.results()
             for p in range(0, sb.num_pairs, 211):
                 o = O.lnw(sb.ref(p), sb.qry(p), 3, -1, -2)
                 assert sc[p] == o.score and np.array_equal(b.matrix(p).astype(np.int32), o.H)
+
+
+def test_packed_row_block_kernel_choice_and_edges(gpu, lanes_kernel, monkeypatch):
+    """k_linear_lanes_pk is chosen for LSW / LNW batches whose weights it can take, never for the others; shapes around its edges:
+    queries of 1..17 rows (the low block empty or one row), references shorter than a lane group's skew, n a multiple of 8 and
+    not, ties between rows of the two blocks of one lane."""
+    monkeypatch.setenv("DPX_QUAD", "1")
+    want = "k_linear_lanes_pk" if lanes_kernel == "packed-row-blocks" else "k_linear_lanes"
+    sb = make_ragged_batch(60, 1, 40, 1, 60, seed=77)
+    for algo, w, kern in (("LSW", (3, -1, -2, -1), want), ("LNW", (3, -1, -2, -1), want), ("LSW", (3, 5, 4, -1), "k_linear_lanes"),
+                          ("LSW", (3, 2, -2, -1), "k_linear_lanes"), ("LNW", (3, 5, 4, -1), want), ("LNW", (2, -40000, -3, -1), "k_linear_lanes")):
+        code = {"LNW": gpu.ALGO_LNW, "LSW": gpu.ALGO_LSW}[algo]
+        with gpu.Batch(code, sb.sequences, sb.pairs, *w) as b:
+            d = b.describe()
+            assert d["kernel"] == kern and d["dtype"] == ("int16" if kern.endswith("_pk") else "int32"), (algo, w, d)
+        _check(gpu, algo, sb, w, every=4)
+    for i, (m, n) in enumerate([(8, 8), (9, 8), (16, 16), (17, 16), (16, 3), (33, 1), (120, 160), (121, 159), (130, 64), (7, 200)]):
+        _check(gpu, "LSW", make_batch(9, m, n, seed=2200 + i, first_index=96), (3, -1, -2, -1))
+        _check(gpu, "LNW", make_batch(9, m, n, seed=2300 + i, first_index=97), (3, -1, -2, -1))
+    same = [(b"0" * 150, b"0" * 40), (b"01" * 60, b"01" * 20), (b"0" * 100, b"1" * 35), (b"0123" * 30, b"3210" * 9)] * 3
+    _check(gpu, "LSW", from_strings(same), (3, -1, -2, -1))
+    _check(gpu, "LSW", from_strings(same), (1, 0, 0, -1))
+    _check(gpu, "LNW", from_strings(same), (1, 0, 0, -1))
