@@ -683,6 +683,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
     int bordG = (2 - skew) * gap; /* NW, first lane of a slot: H[0][j] + gap = (j + 1) * gap, j = t - skew + 1 */
     int rcN = rp[0];
     auto flush = [&]() __attribute__((always_inline)) { /* write out the lines read one step ago */
+#if DPX_EXP_QUAD == 1 /* ablation build (tools/ab_quad.sh): no global stores */
+        if (pendN == 77)
+#endif
 #pragma unroll
         for (int hq = 0; hq < Q; hq++)
             if (hq < pendN) stream_store(reinterpret_cast<u32x4 *>(pendDst + (hq << 9)), pend[hq]);
@@ -703,7 +706,11 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
                 for (int hq = 0; hq < Q; hq++) {
                     u32x4 v = {pack_lo16(h[8 * hq + 0], h[8 * hq + 1]), pack_lo16(h[8 * hq + 2], h[8 * hq + 3]),
                                pack_lo16(h[8 * hq + 4], h[8 * hq + 5]), pack_lo16(h[8 * hq + 6], h[8 * hq + 7])};
+#if DPX_EXP_QUAD != 2
                     *reinterpret_cast<u32x4 *>(putPtr + hq * 64 * kStageLine + (K << 4)) = v;
+#else
+                    pend[hq].y += v.x;
+#endif
                 }
             }
         }
@@ -713,9 +720,17 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
             const uint32_t r = rt[O];
             const bool valid = (uint32_t)t >= (r & 0xFFFFu) && (uint32_t)t <= (r >> 16);
             pendN = valid ? (int)nv[O] : 0;
+#if DPX_EXP_QUAD == 3 /* ablation build: every store instruction full (invalid lines written too): bytes + 50 %, same instruction count */
+            pendN = Q;
+#endif
             pendDst = waveBase + (size_t)t * Stage::kStepElems + (lane << 3);
 #pragma unroll
-            for (int hq = 0; hq < Q; hq++) pend[hq] = *reinterpret_cast<const u32x4 *>(fetchPtr[O] + hq * 64 * kStageLine);
+            for (int hq = 0; hq < Q; hq++)
+#if DPX_EXP_QUAD == 2 /* ablation build: stores without the LDS round trip */
+                pend[hq].x += (uint32_t)t;
+#else
+                pend[hq] = *reinterpret_cast<const u32x4 *>(fetchPtr[O] + hq * 64 * kStageLine);
+#endif
         }
     };
     {
