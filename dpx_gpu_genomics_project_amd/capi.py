@@ -21,7 +21,7 @@ ABI_VERSION_NEEDED = 2  # include/dpx_align.h DPX_ABI_VERSION: the round-2 entry
 
 ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_pool_reserve", "dpx_strerror", "dpx_last_error",
-    "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_sync",
+    "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_last_output_usec", "dpx_batch_sync",
     "dpx_batch_device_results", "dpx_batch_results", "dpx_batch_matrix", "dpx_batch_traceback",
     "dpx_batch_output_begin", "dpx_batch_output_end", "dpx_batch_output_take", "dpx_text_free",
     "dpx_batch_info", "dpx_batch_describe", "dpx_batch_destroy", "dpx_align_batch", "dpx_prim_eval",
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.dpx_batch_fill.argtypes = [vp, vp]
     lib.dpx_batch_fill_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.dpx_batch_last_fill_usec.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.dpx_batch_last_output_usec.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dpx_batch_sync.argtypes = [vp]
     lib.dpx_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.dpx_batch_results.argtypes = [vp, vp, vp, vp]

@@ -356,6 +356,8 @@ struct dpx_batch {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipEvent_t evT0 = nullptr, evT1 = nullptr; /* DPX_TIME_FILLS: recorded around every dpx_batch_fill() */
     hipEvent_t evOrder = nullptr;              /* orders the output path behind a fill that ran on a caller's stream */
+    hipEvent_t evOut0 = nullptr, evOut1 = nullptr; /* DPX_TIME_FILLS: around the traceback + text kernels of dpx_batch_output_begin() */
+    bool outTimed = false;
     bool fillTimed = false;
     hipStream_t lastStream = nullptr; /* stream of the most recent fill (caller's or own) */
     dpx_fill_args args{};
@@ -708,6 +710,8 @@ int dpx_batch_destroy(dpx_batch *b) {
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     if (b->evJoin) (void)hipEventDestroy(b->evJoin);
     if (b->evOrder) (void)hipEventDestroy(b->evOrder);
+    if (b->evOut0) (void)hipEventDestroy(b->evOut0);
+    if (b->evOut1) (void)hipEventDestroy(b->evOut1);
     g_arenaCache.park(b->arena, b->arenaCap);
     g_matCache.park(b->dMat, b->matPoolBytes);
     g_tbDevCache.park(b->dTb, b->dTbCap);
@@ -1413,6 +1417,18 @@ int dpx_batch_last_fill_usec(dpx_batch *b, double *usec) {
     return DPX_OK;
 }
 
+int dpx_batch_last_output_usec(dpx_batch *b, double *usec) {
+    if (!b || !usec) return DPX_ERR_INVALID;
+    if (!b->outTimed) return DPX_ERR_NOT_FILLED; /* no dpx_batch_output_begin() yet, or the batch was created without DPX_TIME_FILLS */
+    int rc = bind_device(b->device);
+    if (rc != DPX_OK) return rc;
+    HIP_TRY(hipEventSynchronize(b->evOut1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->evOut0, b->evOut1));
+    *usec = (double)ms * 1000.0;
+    return DPX_OK;
+}
+
 int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     if (!b || repeats < 1 || !usecPerFill) return DPX_ERR_INVALID;
     int rc = bind_device(b->device);
@@ -1517,6 +1533,12 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         HIP_TRY(hipEventRecord(b->evOrder, b->lastStream));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->evOrder, 0));
     }
+    const bool timeOut = (b->flags & DPX_TIME_FILLS) != 0;
+    if (timeOut) {
+        if (!b->evOut0) HIP_TRY(hipEventCreate(&b->evOut0));
+        if (!b->evOut1) HIP_TRY(hipEventCreate(&b->evOut1));
+        HIP_TRY(hipEventRecord(b->evOut0, b->stream));
+    }
     if (!b->tbLinesValid) {
         /* How to walk: one lane per pair -- through register-cached column vectors (walk 1) when there are enough lanes in flight
          * to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster), cell by cell (walk
@@ -1537,6 +1559,7 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
     HIP_TRY(dpx_launch_output(b->dPairs, b->dScore, b->dTbLen, b->dTbOff, b->dTb, (int)np, (unsigned long long)firstNumber,
                               reinterpret_cast<unsigned long long *>(b->dOutScratch), reinterpret_cast<unsigned long long *>(b->dOutOff), b->dOut,
                               false, false, b->stream));
+    if (timeOut) { HIP_TRY(hipEventRecord(b->evOut1, b->stream)); b->outTimed = true; }
     if (np) {
         HIP_TRY(hipMemcpyAsync(hOff, b->dOutOff, (np + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipMemcpyAsync(hLen, b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));

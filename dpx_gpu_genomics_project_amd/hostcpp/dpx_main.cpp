@@ -124,6 +124,7 @@ int main(int argc, char *argv[]) {
     if (reserve.joinable()) reserve.join();
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
+    uint64_t traceback_kernel_time = 0; // device time of the traceback + text kernels (backtracking_time is the host's wait for them)
     printf("Pair # | Score\n");
     const dpx_params prm{algo, match, mismatch, gapOpen, gapExtend, band};
     static_assert(sizeof(seqPair) == sizeof(dpx_seq_pair), "seqPair must stay layout-compatible with the C ABI");
@@ -148,6 +149,7 @@ int main(int argc, char *argv[]) {
         double usec = 0;
         if ((rc = dpx_batch_last_fill_usec(f.b, &usec)) != DPX_OK) die("KERNEL TIMING FAILED", rc);
         kernel_time += (uint64_t)usec;
+        if (print && dpx_batch_last_output_usec(f.b, &usec) == DPX_OK) traceback_kernel_time += (uint64_t)usec;
         backtracking_time += get_time() - t0;
         t0 = get_time();
         dpx_batch_destroy(f.b);
@@ -194,6 +196,7 @@ int main(int argc, char *argv[]) {
     printf("Kernel time (usec): %llu\n", (unsigned long long)kernel_time);
     printf("Memory management time (usec): %llu\n", (unsigned long long)memalloc_time);
     printf("Backtracking time (usec): %llu\n", (unsigned long long)backtracking_time);
+    printf("Traceback kernel time (usec): %llu\n", (unsigned long long)traceback_kernel_time);
     printf("Printing wait time (usec): %llu\n", (unsigned long long)printing_time);
     // GCUPS exactly as the reference computes it (V12.cu:487-491): numCells / kernel seconds / 1e9
     printf("GCUPS: %f\n", kernel_time ? (double)shardCells / ((double)kernel_time * 1e-6) / 1e9 : 0.0);

@@ -72,8 +72,9 @@ typedef struct dpx_params {
 #define DPX_KEEP_MATRICES 0x0u /* default: write the int16 score matrices (H; H,I,D for ANW) to HBM */
 #define DPX_SCORE_ONLY    0x1u /* no matrix writeback (not HBM-bound; never used for the roofline figure) */
 #define DPX_TIME_FILLS    0x2u /* bracket every dpx_batch_fill() with HIP events: dpx_batch_last_fill_usec() */
-#define DPX_TUNE_PLACEMENT 0x4u /* the batch will be filled many times: spend up to five extra allocations of the matrix pool (>= 1 GiB)
-                                   to pick a well-placed one -- where a big allocation lands in HBM is worth +-4 % of write bandwidth */
+#define DPX_TUNE_PLACEMENT 0x4u /* the batch will be filled many times: time its matrix pool (>= 1 GiB) with hipMemset and shop for a better
+                                   one with the batch's OWN FILL on up to three more candidate pools (the same fill runs 2 - 27 % apart on
+                                   two pools of the same construction); every candidate's times go into dpx_batch_describe's pool_* fields */
 
 /* matrix selectors for dpx_batch_matrix */
 #define DPX_MAT_H 0 /* scoring matrix   (reference: memo / scoringMemo)            */
@@ -111,9 +112,9 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
 
 /* The same on an explicit device (0 .. dpx_device_count()-1; -1 = the default device): one host process can drive
  * several GPUs, each batch lives on the device it was created on and every call on it runs there.  The class surface
- * uses this to spread the batches it forms from the reference's 20 threads over all visible devices (hostcpp/DpxPair.cpp),
- * so the unchanged c++/main.cpp uses a whole node; one process per GPU (dpx_init(rank)) remains the layout of the
- * batched driver and of bench.py.  device >= count is DPX_ERR_INVALID. */
+ * uses this to spread the batches it forms from the reference's 20 threads over all visible devices (hostcpp/DpxPair.cpp;
+ * rehearsed with several leaders on one GPU only, never run on a multi-GPU box); one process per GPU (dpx_init(rank)) remains
+ * the layout of the batched driver and of bench.py.  device >= count is DPX_ERR_INVALID. */
 int dpx_batch_create_on(int device, const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
                         size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
 
@@ -133,6 +134,9 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill);
  * the events are recorded on the fill's stream, this call waits only for the second one (the reference accumulates
  * kernel_time the same way around its launches, V19.cu:531-586, but synchronously). */
 int dpx_batch_last_fill_usec(dpx_batch *b, double *usec);
+/* The same for the device side of the most recent dpx_batch_output_begin(): traceback + text kernels (the reference's
+ * backtracking() launch, V19.cu:546-560), without the D2H copies. */
+int dpx_batch_last_output_usec(dpx_batch *b, double *usec);
 
 int dpx_batch_sync(dpx_batch *b); /* cudaDeviceSynchronize analogue for this batch's stream */
 

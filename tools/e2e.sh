@@ -17,6 +17,6 @@ for algo in LSW LNW ANW; do
   EXT=""; OPEN=-2; [ $algo = ANW ] && EXT="-extend -1" && OPEN=-3
   echo "== $algo $N pairs ($SHAPE), print to file"
   dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT $BATCHARG ${E2E_EXTRA:-} > /tmp/e2e_out.txt
-  grep -E "^Elapsed|^Kernel|^Memory|^Backtracking|^Printing|^GCUPS" /tmp/e2e_out.txt | tr '\n' ' '; echo
+  grep -E "^Elapsed|^Kernel|^Memory|^Backtracking|^Traceback|^Printing|^GCUPS" /tmp/e2e_out.txt | tr '\n' ' '; echo
   ls -la /tmp/e2e_out.txt | awk '{print "output bytes", $5}'
 done
