@@ -17,7 +17,7 @@ KEEP_MATRICES, SCORE_ONLY, TIME_FILLS, TUNE_PLACEMENT = 0x0, 0x1, 0x2, 0x4
 MAT_H, MAT_I, MAT_D = 0, 1, 2
 
 # every symbol include/dpx_align.h declares (tests check the .so exports all of them)
-ABI_VERSION_NEEDED = 2  # include/dpx_align.h DPX_ABI_VERSION: the round-2 entry points + the pool record in dpx_batch_describe
+ABI_VERSION_NEEDED = 3  # include/dpx_align.h DPX_ABI_VERSION: round-3 entry points (dpx_pool_reserve, dpx_batch_last_output_usec) + the pool record in dpx_batch_describe
 
 ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_pool_reserve", "dpx_strerror", "dpx_last_error",

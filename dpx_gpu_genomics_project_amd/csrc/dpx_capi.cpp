@@ -104,7 +104,7 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     r.device = t_device;
     void *va = nullptr;
     hipError_t e = hipMemAddressReserve(&va, r.bytes, 0, nullptr, 0);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipMalloc(out, bytes); }
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof prop);
     prop.type = hipMemAllocationTypePinned;
@@ -130,7 +130,10 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     }
     if (e != hipSuccess) {
         vmm_release(va, r, mapped);
-        return e;
+        if (e == hipErrorOutOfMemory) return e;
+        /* a runtime without (working) virtual-memory management: one hipMalloc, as before round 3 -- slower to write, never wrong */
+        (void)hipGetLastError();
+        return hipMalloc(out, bytes);
     }
     { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(va, std::move(r)); }
     t_poolStats.mode = "vmm";

@@ -2032,11 +2032,50 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
  * I, D leave through the same LDS line stage into the 8 x 8 tile layout, three whole-line stores per step.  One wave per
  * workgroup: the stage needs 27 KiB of LDS per wave (three planes), so small workgroups keep five of them on a CU. */
 #define DPX_ALANES_THREADS 64
+/* Round 3: the cell update keeps its state as H + (o+e), I + e, D + e (aff_cells_g: 9 vector instructions per cell instead of 10, rows
+ * in place), eight steps per trip, routing in registers, loop control on the scalar unit -- as in k_linear_lanes.  Tried and dropped:
+ * a HALF-LINE stage (4 columns per lane and plane, 15 KiB of LDS per wave instead of 27: ten waves per CU instead of five; the two
+ * 64-byte halves of a line stored four steps apart by the same wave) -- bit-exact, 2.42 ms instead of 1.67 on 100k short reads: a
+ * 128-byte line that is written in two pieces costs far more than the residency buys. */
+
+template <int R>
+struct AffStateG {
+    int Hoe[R], Ie[R]; /* H[row][j-1] + (o+e), I[row][j-1] + e */
+    int qc[R];
+    int dtopOe;        /* H[row0][j-1] + (o+e) */
+    int DeLast;        /* D[row0+R][j] + e of the column just computed (the next lane's "D above") */
+};
+
+/* D = max(H_up + oe, D_up + e);  I = max(H_left + oe, I_left + e);  H = max3(D, H_diag + s, I)   (c++/AffineNeedlemanWunsch.cpp:185-236) */
+template <int R>
+__device__ __forceinline__ void aff_cells_g(AffStateG<R> &st, const int upHoe, const int upDe, const int rc, const int matchG, const int mismatchG,
+                                            const int oe, const int e, int (&Hv)[R], int (&Iv)[R], int (&Dv)[R]) {
+    int dterm[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) dterm[r] = ((r == 0) ? st.dtopOe : st.Hoe[r - 1]) + ((st.qc[r] == rc) ? matchG : mismatchG); /* (s - oe) */
+    int ug = upHoe, ud = upDe;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int Dn = max(ug, ud);
+        const int In = max(st.Hoe[r], st.Ie[r]);
+        const int h = max(max(Dn, dterm[r]), In); /* v_max3_i32 */
+        Hv[r] = h; Iv[r] = In; Dv[r] = Dn;
+        ug = h + oe;
+        ud = Dn + e;
+        st.Hoe[r] = ug;
+        st.Ie[r] = In + e;
+    }
+    st.DeLast = ud;
+    st.dtopOe = upHoe;
+}
+
 template <int R, bool STORE>
 __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_fill_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int Q = R / 8;
-    using Stage = LineStage<Q, 3>;
+    static_assert(R == 8, "one 8-row block per lane");
+    constexpr int kPlane = 64 * kStageLine; /* bytes of one plane's lines */
+    constexpr int kStageBytes = 3 * kPlane;
+    constexpr int kStepElems = 3 * 512;     /* int16 elements of one chunk of the wave's stream (dpx_layout.h) */
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * (DPX_ALANES_THREADS / 64) + wv;
@@ -2046,80 +2085,118 @@ __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_f
     const int p = sl.p, l = sl.l;
     const dpx_pair_dev pr = a.pairs[p];
     const int n = has ? pr.n : 0, m = has ? pr.m : 0;
-    const int match = a.match, mismatch = a.mismatch;
     const int o = a.gapOpen, e = a.gapExtend, oe = o + e;
+    const int matchG = a.match - oe, mismatchG = a.mismatch - oe;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
     unsigned char *tileL = smem + (size_t)wv * a.ldsPerWave;
-    unsigned char *refl = tileL + (STORE ? Stage::kBytes : kLaneScratch) + sl.refOff;
+    unsigned char *refl = tileL + (STORE ? kStageBytes : kLaneScratch) + sl.refOff;
     const unsigned char *refs = stage_bytes(refl, ref, n, l, max(sl.num, 1));
 
     const int row0 = l * R;
     const int nrows = min(max(m - row0, 0), R);
-    AffState<R> st;
+    AffStateG<R> st;
     load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        st.Hl[r] = o + (row0 + 1 + r) * e; /* H[i][0] = o + i*e (AffineNeedlemanWunsch.cpp:43-46) */
-        st.Il[r] = DPX_NEG;                /* virtual I[i][0] */
-        st.Dl[r] = DPX_NEG;
+        st.Hoe[r] = o + (row0 + 1 + r) * e + oe; /* H[i][0] = o + i*e (AffineNeedlemanWunsch.cpp:43-46) */
+        st.Ie[r] = DPX_NEG + e;                  /* virtual I[i][0] */
     }
-    st.dtop = row0 == 0 ? 0 : o + row0 * e; /* H[0][0] = 0 */
+    st.dtopOe = (row0 == 0 ? 0 : o + row0 * e) + oe; /* H[0][0] = 0 */
+    st.DeLast = DPX_NEG + e;
 
-    const int skew = l + sl.d;
+    const int skew = l + sl.d; /* this lane runs column j = t - skew + 1 in step t; skew = lane (mod 8) */
     const int n8 = (n + 7) & ~7;
     const int LB = (int)dpx_tile8_row_blocks(m);
-    if constexpr (STORE) Stage::set_route(tileL, lane, skew, n8, has ? min(max(LB - l * Q, 0), Q) : 0);
+    /* routing, once: a lane's lines are complete in the steps skew + 7, skew + 15, ... <= n8 + skew - 1 (first | last << 16); every lane
+     * keeps the words of the eight lanes of its group in registers */
+    uint32_t rt[8];
+    if constexpr (STORE) {
+        const bool rowsHere = has && (LB - l) > 0;
+        uint32_t *mine = reinterpret_cast<uint32_t *>(tileL + lane * kStageLine + 128);
+        mine[0] = rowsHere ? ((uint32_t)(skew + 7) | ((uint32_t)(n8 + skew - 1) << 16)) : 0x00007FFFu; /* (never valid: first > last) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 8; k++) rt[k] = *reinterpret_cast<const uint32_t *>(tileL + ((lane & ~7) | k) * kStageLine + 128);
+    }
     int16_t *waveBase = a.mat + (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff >> 32)) << 32) |
                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pr.matOff & 0xFFFFFFFFull)));
-    const int steps = wave_max_i32(has ? (STORE ? n8 : n) + skew : 0);
+    const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (STORE ? n8 : n) + skew : 0));
     const unsigned char *rp = refs - skew;
+    const unsigned nEff = nrows > 0 ? (unsigned)n : 0u;
+    unsigned char *putPtr = tileL + lane * kStageLine; /* + plane * kPlane + (t & 7) * 16 */
+    const unsigned char *fetchPtr[8]; /* piece lane % 8 of the line of lane k of this lane's group, rotated by its owner (see k_linear_lanes) */
+#pragma unroll
+    for (int k = 0; k < 8; k++) fetchPtr[k] = tileL + ((lane & ~7) | k) * kStageLine + (((lane + k) & 7) << 4);
+    u32x4 pend[3];
+    bool pendOk = false;
+    int16_t *pendDst = nullptr;
+    int bordOe = o + (1 - skew) * e + oe; /* first lane of a slot: H[0][j] + (o+e), j = t - skew + 1 */
     int rcN = rp[0];
-    Stage stage;
-    if constexpr (STORE) stage.fetch_route(tileL, lane, 0);
-    auto pack8 = [](const int *v) -> u32x4 {
-        u32x4 w = {pack_lo16(v[0], v[1]), pack_lo16(v[2], v[3]), pack_lo16(v[4], v[5]), pack_lo16(v[6], v[7])};
-        return w;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (pendOk) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) stream_store(reinterpret_cast<u32x4 *>(pendDst + (pl << 9)), pend[pl]);
+        }
     };
-    auto lane_step = [&](const int t) {
-        const int j = t - skew + 1;
+    auto pack8 = [](const int (&v)[R]) __attribute__((always_inline)) -> u32x4 {
+        u32x4 x = {pack_lo16(v[0], v[1]), pack_lo16(v[2], v[3]), pack_lo16(v[4], v[5]), pack_lo16(v[6], v[7])};
+        return x;
+    };
+    auto lane_step = [&](const int t, auto kTag) __attribute__((always_inline)) {
+        constexpr int K = decltype(kTag)::value; /* t & 7 */
+        const int tms = t - skew;
         const int rc = rcN;
         rcN = rp[t + 1];
-        const int shH = wave_shr1(st.Hl[R - 1], 0), shD = wave_shr1(st.Dl[R - 1], 0);
-        const int upH = (l == 0) ? o + j * e : shH;   /* row-0 border H[0][j] = o + j*e (:50-53) */
-        const int upD = (l == 0) ? DPX_NEG : shD;     /* virtual D[0][j] */
-        const bool active = nrows > 0 && j >= 1 && j <= n;
-        if (active) aff_cells<R>(st, upH, upD, rc, match, mismatch, oe, e);
-        if constexpr (STORE) {
-            if (active) {
-#pragma unroll
-                for (int h = 0; h < Q; h++) {
-                    Stage::put(tileL, lane, 0, h, t, pack8(&st.Hl[8 * h]));
-                    Stage::put(tileL, lane, 1, h, t, pack8(&st.Il[8 * h]));
-                    Stage::put(tileL, lane, 2, h, t, pack8(&st.Dl[8 * h]));
-                }
+        const int shH = wave_shr1(st.Hoe[R - 1], 0), shD = wave_shr1(st.DeLast, 0);
+        const int upHoe = (l == 0) ? bordOe : shH;          /* row-0 border H[0][j] = o + j*e (:50-53) */
+        const int upDe = (l == 0) ? (DPX_NEG + e) : shD;    /* virtual D[0][j] */
+        bordOe += e;
+        if ((unsigned)tms < nEff) {
+            int Hv[R], Iv[R], Dv[R];
+            aff_cells_g<R>(st, upHoe, upDe, rc, matchG, mismatchG, oe, e, Hv, Iv, Dv);
+            if constexpr (STORE) {
+                *reinterpret_cast<u32x4 *>(putPtr + 0 * kPlane + (K << 4)) = pack8(Hv);
+                *reinterpret_cast<u32x4 *>(putPtr + 1 * kPlane + (K << 4)) = pack8(Iv);
+                *reinterpret_cast<u32x4 *>(putPtr + 2 * kPlane + (K << 4)) = pack8(Dv);
             }
-            stage.store();
-            stage.fetch(tileL, waveBase, lane, t);
-            stage.fetch_route(tileL, lane, t + 1);
+        }
+        if constexpr (STORE) {
+            flush();
+            constexpr int O = (K + 1) & 7; /* the owners of the lines that are complete now */
+            const uint32_t r = rt[O];
+            pendOk = (uint32_t)t >= (r & 0xFFFFu) && (uint32_t)t <= (r >> 16);
+            pendDst = waveBase + (size_t)t * kStepElems + (lane << 3);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) pend[pl] = *reinterpret_cast<const u32x4 *>(fetchPtr[O] + pl * kPlane);
         }
     };
     {
         int t = 0;
-        for (; t + 1 < steps; t += 2) {
-            lane_step(t);
-            lane_step(t + 1);
+        for (; t + 8 <= steps; t += 8) {
+            lane_step(t + 0, std::integral_constant<int, 0>{}); lane_step(t + 1, std::integral_constant<int, 1>{});
+            lane_step(t + 2, std::integral_constant<int, 2>{}); lane_step(t + 3, std::integral_constant<int, 3>{});
+            lane_step(t + 4, std::integral_constant<int, 4>{}); lane_step(t + 5, std::integral_constant<int, 5>{});
+            lane_step(t + 6, std::integral_constant<int, 6>{}); lane_step(t + 7, std::integral_constant<int, 7>{});
         }
-        if (t < steps) lane_step(t);
+        if (t + 0 < steps) lane_step(t + 0, std::integral_constant<int, 0>{});
+        if (t + 1 < steps) lane_step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < steps) lane_step(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < steps) lane_step(t + 3, std::integral_constant<int, 3>{});
+        if (t + 4 < steps) lane_step(t + 4, std::integral_constant<int, 4>{});
+        if (t + 5 < steps) lane_step(t + 5, std::integral_constant<int, 5>{});
+        if (t + 6 < steps) lane_step(t + 6, std::integral_constant<int, 6>{});
     }
-    if constexpr (STORE) stage.store();
+    if constexpr (STORE) flush();
     const int lm = (m - 1) / R, rm = (m - 1) % R;
     if (has && l == lm) {
-        int v = st.Hl[0];
+        int v = st.Hoe[0];
 #pragma unroll
-        for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-        a.score[p] = v; /* scoringMemo[m][n] (:365) */
+        for (int r = 1; r < R; r++) v = (r == rm) ? st.Hoe[r] : v;
+        a.score[p] = v - oe; /* scoringMemo[m][n] (:365); the state is H + (o+e) */
         a.endRow[p] = m;
         a.endCol[p] = n;
     }

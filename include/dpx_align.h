@@ -23,9 +23,10 @@ extern "C" {
 #endif
 
 /* 1: round 1.  2: + dpx_batch_create_on, dpx_batch_fill_timed, dpx_batch_last_fill_usec, dpx_batch_output_begin/_end/_take,
- * dpx_text_free, DPX_TUNE_PLACEMENT (round 2); dpx_batch_describe reports the matrix pool (round 3).  Additions only: a caller
- * built against version 1 keeps working; dpx_abi_version() >= the version a caller needs is the check. */
-#define DPX_ABI_VERSION 2
+ * dpx_text_free, DPX_TUNE_PLACEMENT (round 2).  3: + dpx_pool_reserve, dpx_batch_last_output_usec; dpx_batch_describe reports the
+ * matrix pool (round 3).  Additions only: a caller built against an older version keeps working; dpx_abi_version() >= the version
+ * a caller needs is the check. */
+#define DPX_ABI_VERSION 3
 
 typedef enum dpx_status {
     DPX_OK = 0,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = dpx.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dpx_abi_version() == 2
+    assert lib.dpx_abi_version() == 3
     assert lib.dpx_strerror(-2).decode().startswith("no usable HIP device")
 
 
