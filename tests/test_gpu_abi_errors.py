@@ -79,3 +79,21 @@ def test_explicit_device_argument(gpu):
                 o = O.lsw(sb.ref(p), sb.qry(p))
                 assert (sc[p], er[p], ec[p]) == (o.score, o.end_row, o.end_col)
                 assert np.array_equal(b.matrix(p).astype(np.int32), o.H)
+
+
+def test_output_timing_needs_the_flag_and_an_output_run(gpu):
+    """dpx_batch_last_output_usec (round 3): device time of the traceback + text kernels of the last dpx_batch_output_begin() of a
+    batch created with DPX_TIME_FILLS -- DPX_ERR_NOT_FILLED before that / without the flag."""
+    lib = gpu.load()
+    sb = make_batch(64, 200, 220, seed=5)
+    us = C.c_double(-1)
+    with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, flags=gpu.TIME_FILLS) as b:
+        b.fill()
+        assert lib.dpx_batch_last_output_usec(b._h, C.byref(us)) == -6
+        assert lib.dpx_batch_output_begin(b._h, 0) == 0
+        assert lib.dpx_batch_last_output_usec(b._h, C.byref(us)) == 0 and 1.0 < us.value < 1e6
+        assert lib.dpx_batch_last_output_usec(b._h, None) == -1
+    with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs) as b:
+        b.fill()
+        assert lib.dpx_batch_output_begin(b._h, 0) == 0
+        assert lib.dpx_batch_last_output_usec(b._h, C.byref(us)) == -6
