@@ -216,6 +216,32 @@ __device__ __forceinline__ void lin_cells(LinState<R, LOCAL> &st, const int upin
     st.dtop = upin;
 }
 
+/* The cell update of the int32 kernels (round 3; k_linear_stream still uses lin_cells).  The lane's state is kept as Hg = H + gap: then
+ *     H[r][j] = max3(Hg[r-1][j], Hg[r][j-1], Hg[r-1][j-1] + (s - gap))          (one v_max3_i32, SW: the diagonal term clamped at 0 first)
+ * and Hg[r][j] = H[r][j] + gap is the only op left on the chain from one row to the next: 5 vector instructions per NW cell
+ * instead of 6 (v_cmp, v_cndmask, v_add, v_max3, v_add), two dependent ones per row instead of three.  The diagonal terms are
+ * computed first and every row is updated in place (no register rotation, see lin_cells).  h[] returns the plain scores. */
+template <int R, bool LOCAL>
+__device__ __forceinline__ void lin_cells_g(LinState<R, LOCAL> &st, const int upinG, const int rc, const unsigned negj, const int matchG,
+                                            const int mismatchG, const int gap, int (&h)[R]) {
+    int dterm[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        dterm[r] = ((r == 0) ? st.dtop : st.Hl[r - 1]) + ((st.qc[r] == rc) ? matchG : mismatchG);
+        if constexpr (LOCAL) dterm[r] = max(dterm[r], 0);
+    }
+    int ug = upinG;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int v = max(max(ug, st.Hl[r]), dterm[r]); /* v_max3_i32 */
+        h[r] = v;
+        ug = v + gap;
+        st.Hl[r] = ug;
+        if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)v << 16) | negj);
+    }
+    st.dtop = upinG;
+}
+
 /* pack the lane's R scores into R/2 dwords (the store format) */
 template <int R, bool LOCAL>
 __device__ __forceinline__ void lin_pack(LinState<R, LOCAL> &st, uint32_t (&w)[(R + 1) / 2]) {
@@ -259,24 +285,27 @@ __device__ __forceinline__ void lin_fold_keys(const LinState<R, LOCAL> &st, cons
  * SW tracks per-row (score, column) keys in registers, so the start cell needs no second pass over the matrix. */
 template <int R, bool LOCAL, bool STORE, bool MASKED, bool WHOLE>
 __device__ __forceinline__ void lin_step(LinState<R, LOCAL> &st, const int t, const int lane, const int n,
-                                         const bool laneHasRows, const int match, const int mismatch, const int gap,
+                                         const bool laneHasRows, const int matchG, const int mismatchG, const int gap,
                                          const int e0, const int rc, int16_t *edge, const bool writeEdge,
                                          int16_t *tileDst, const int storeLanes, const int rampLines) {
+    /* the state is H + gap (lin_cells_g); e0 = the plain H of the row above lane 0 (edge row / row-0 border) */
     const int j = t - lane + 1;
     /* cross-lane traffic happens with all lanes enabled: a finished lane must still feed its neighbour */
-    const int upin = wave_shr1(st.Hl[R - 1], e0);
+    const int upin = wave_shr1(st.Hl[R - 1], e0 + gap);
     bool active = true;
     if constexpr (MASKED) active = laneHasRows && (j >= 1) && (j <= n);
     uint32_t w[(R + 1) / 2];
     if (active) {
-        lin_cells<R, LOCAL, true>(st, upin, rc, j, match, mismatch, gap);
-        if (writeEdge && lane == 63) edge[j] = (int16_t)st.Hl[R - 1];
+        int h[R];
+        lin_cells_g<R, LOCAL>(st, upin, rc, 0xFFFFu - (unsigned)j, matchG, mismatchG, gap, h);
+        if (writeEdge && lane == 63) edge[j] = (int16_t)h[R - 1];
         if constexpr (STORE) {
-            lin_pack<R, LOCAL>(st, w);
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) w[q] = pack_lo16(h[2 * q], h[2 * q + 1]);
             if constexpr (MASKED && !WHOLE) store_words<R>(tileDst, w);
         }
     } else if constexpr (STORE) {
-        lin_pack<R, LOCAL>(st, w);
+        lin_pack<R, LOCAL>(st, w); /* (a lane that is not on a cell stores into padding that nothing reads: any value) */
     }
     /* Every lane stores, also lanes that are not on a real cell during the skew ramps: the wave then always writes
      * its whole 64*R*2-byte chunk.  Partial chunks (masked stores) measured ~2.5x the cost of full ones -- a chunk
@@ -299,7 +328,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
     if (a.order) p = a.order[p];
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
-    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
+    const int gap = a.gapOpen, matchG = a.match - gap, mismatchG = a.mismatch - gap; /* the lanes' state is H + gap (lin_cells_g) */
 
     if (m <= 0 || n <= 0) { /* empty sequence: only borders exist */
         if (lane == 0) {
@@ -337,10 +366,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
         load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+            st.Hl[r] = (LOCAL ? 0 : (row0 + 1 + r) * gap) + gap;
             st.key[r] = 0u;
         }
-        st.dtop = LOCAL ? 0 : row0 * gap;
+        st.dtop = (LOCAL ? 0 : row0 * gap) + gap;
         int j0 = 1;      /* lane 0's column (wave-uniform): index of its `up` in the edge row */
         bool sw = false; /* this lane wrapped at the end of the previous step */
         int rcN = refl[63 + jl];
@@ -354,7 +383,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             j0 = (j0 >= n) ? 1 : j0 + 1;
             e0N = edge[j0]; /* read n-64 steps after lane 63 wrote it, 63 steps before lane 63 overwrites it */
             /* the neighbour's bottom row must be taken BEFORE a switching lane resets its registers */
-            const int upin = wave_shr1(st.Hl[R - 1], e0);
+            const int upin = wave_shr1(st.Hl[R - 1], e0 + gap);
             if (sw) { /* stripe switch (one lane per step for 64 steps around each stripe boundary) */
                 if constexpr (LOCAL) {
                     lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
@@ -364,16 +393,20 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     st.qc[r] = (r < nrows) ? (int)ql[row0 + r] : 0x100;
-                    st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
+                    st.Hl[r] = (LOCAL ? 0 : (row0 + 1 + r) * gap) + gap;
                     st.key[r] = 0u;
                 }
-                st.dtop = LOCAL ? 0 : row0 * gap;
+                st.dtop = (LOCAL ? 0 : row0 * gap) + gap;
             }
             uint32_t w[(R + 1) / 2];
             if (jl >= 1 && kl < S && nrows > 0) {
-                lin_cells<R, LOCAL, true>(st, upin, rc, jl, match, mismatch, gap);
-                if (lane == 63 && kl + 1 < S) edge[jl] = (int16_t)st.Hl[R - 1];
-                if constexpr (STORE) lin_pack<R, LOCAL>(st, w);
+                int h[R];
+                lin_cells_g<R, LOCAL>(st, upin, rc, 0xFFFFu - (unsigned)jl, matchG, mismatchG, gap, h);
+                if (lane == 63 && kl + 1 < S) edge[jl] = (int16_t)h[R - 1];
+                if constexpr (STORE) {
+#pragma unroll
+                    for (int q = 0; q < R / 2; q++) w[q] = pack_lo16(h[2 * q], h[2 * q + 1]);
+                }
             } else if constexpr (STORE) {
                 lin_pack<R, LOCAL>(st, w);
             }
@@ -403,10 +436,10 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             load_query_rows<R>(st.qc, qry, row0, nrows);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 */
+                st.Hl[r] = (LOCAL ? 0 : (row0 + 1 + r) * gap) + gap; /* column-0 border, LinearNeedlemanWunsch.cpp:31-34 (+ gap: lin_cells_g) */
                 st.key[r] = 0u;
             }
-            st.dtop = LOCAL ? 0 : row0 * gap;
+            st.dtop = (LOCAL ? 0 : row0 * gap) + gap;
             int16_t *tile = Hp + (size_t)k * (size_t)n * cs + (size_t)lane * (R < 8 ? R : 8);
 
             /* software pipeline: the LDS reads of step t+1 (reference character of the lane's next column, and
@@ -419,7 +452,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
                 const int rc = rcN, e0 = e0N;                                                                         \
                 rcN = rp[(T_) + 1];                                                                                   \
                 e0N = edge[min((T_) + 2, n + 1)];                                                                     \
-                lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, (T_), lane, n, HASROWS_, match, mismatch, gap, e0, rc, edge, \
+                lin_step<R, LOCAL, STORE, MASKED_, WHOLE_>(st, (T_), lane, n, HASROWS_, matchG, mismatchG, gap, e0, rc, edge, \
                                                            hasNext, tile + (size_t)(T_) * cs, storeLanes, a.rampLines); \
             }
             const bool fast = (base + 64 * R <= m) && (n >= 64);
@@ -465,7 +498,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
             int v = st.Hl[0];
 #pragma unroll
             for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-            a.score[p] = v;
+            a.score[p] = v - gap; /* (the state is H + gap) */
             a.endRow[p] = m;
             a.endCol[p] = n;
         }
@@ -581,32 +614,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
     return v;
-}
-
-/* The cell update of the lane-packed linear kernels (round 3).  The lane's state is kept as Hg = H + gap: then
- *     H[r][j] = max3(Hg[r-1][j], Hg[r][j-1], Hg[r-1][j-1] + (s - gap))          (one v_max3_i32, SW: the diagonal term clamped at 0 first)
- * and Hg[r][j] = H[r][j] + gap is the only op left on the chain from one row to the next: 5 vector instructions per NW cell
- * instead of 6 (v_cmp, v_cndmask, v_add, v_max3, v_add), two dependent ones per row instead of three.  The diagonal terms are
- * computed first and every row is updated in place (no register rotation, see lin_cells).  h[] returns the plain scores. */
-template <int R, bool LOCAL>
-__device__ __forceinline__ void lin_cells_g(LinState<R, LOCAL> &st, const int upinG, const int rc, const unsigned negj, const int matchG,
-                                            const int mismatchG, const int gap, int (&h)[R]) {
-    int dterm[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        dterm[r] = ((r == 0) ? st.dtop : st.Hl[r - 1]) + ((st.qc[r] == rc) ? matchG : mismatchG);
-        if constexpr (LOCAL) dterm[r] = max(dterm[r], 0);
-    }
-    int ug = upinG;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int v = max(max(ug, st.Hl[r]), dterm[r]); /* v_max3_i32 */
-        h[r] = v;
-        ug = v + gap;
-        st.Hl[r] = ug;
-        if constexpr (LOCAL) st.key[r] = max(st.key[r], ((unsigned)v << 16) | negj);
-    }
-    st.dtop = upinG;
 }
 
 template <int R, bool LOCAL, bool STORE>
