@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
     const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (STORE ? n8 : n) + skew : 0)); /* uniform: the loop runs on the scalar unit */
     const unsigned char *rp = refs - skew; /* rp[t] = reference character of column j = t - skew + 1 */
     const unsigned nEff = nrows > 0 ? (unsigned)n : 0u; /* the lane is on a cell iff (unsigned)(t - skew) < nEff */
+    const int rpLast = n + skew;                        /* rp[rpLast] = refs[n]: inside the 31 bytes of slack of stage_bytes */
     unsigned char *putPtr = tileL + lane * kStageLine;             /* + sub-tile * 64 lines + (t & 7) * 16 */
     const unsigned char *fetchPtr[8];                              /* piece lane % 8 of the line of lane k of this lane's group, rotated by its owner */
 #pragma unroll
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
         constexpr int K = decltype(kTag)::value; /* t & 7 */
         const int tms = t - skew;
         const int rc = rcN;
-        rcN = rp[t + 1];
+        rcN = rp[min(t + 1, rpLast)]; /* (never past the slot's staged reference: a shorter pair's lane idles to the end of the wave) */
         const int sh = wave_shr1(st.Hl[R - 1], 0);
         const int upinG = (l == 0) ? (LOCAL ? gap : bordG) : sh; /* a slot's first lane: row-0 border of its column (+ gap) */
         if constexpr (!LOCAL) bordG += gap;
@@ -1464,6 +1465,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
     const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(lastStep)) + 1;
     const unsigned char *rp = refs - skew; /* rp[t] = reference character of the high half's column */
     const unsigned nEff = nrows > 8 ? (unsigned)n + 1u : (nrows > 0 ? (unsigned)n : 0u); /* on a cell iff (unsigned)(t - skew) < nEff */
+    const int rpLast = n + skew; /* rp[rpLast] = refs[n]: inside the slack of stage_bytes (never read past the slot's staged reference) */
     unsigned char *putPtr = tileL + lane * kStageLine;
     const unsigned char *fetchPtr[8]; /* piece lane % 8 of the high-block line of lane k of this lane's group (low block: + 64 lines) */
 #pragma unroll
@@ -1483,7 +1485,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
         const int tms = t - skew;
         const uint32_t rcP = (rcCur << 16) | rcPrev; /* {character of column j, of column j-1} */
         rcPrev = rcCur;
-        rcCur = rp[t + 1];
+        rcCur = rp[min(t + 1, rpLast)];
         const uint32_t sh = (uint32_t)wave_shr1((int)Hl[7], 0);
         uint32_t upin = __builtin_amdgcn_perm(sh, Hl[7], 0x05040302u); /* {previous lane's low half, this lane's high half} */
         if constexpr (!LOCAL) bord = (uint32_t)(uint16_t)(bord + (uint32_t)gap);
@@ -2134,6 +2136,7 @@ __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_f
     const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (STORE ? n8 : n) + skew : 0));
     const unsigned char *rp = refs - skew;
     const unsigned nEff = nrows > 0 ? (unsigned)n : 0u;
+    const int rpLast = n + skew; /* rp[rpLast] = refs[n]: inside the slack of stage_bytes */
     unsigned char *putPtr = tileL + lane * kStageLine; /* + plane * kPlane + (t & 7) * 16 */
     const unsigned char *fetchPtr[8]; /* piece lane % 8 of the line of lane k of this lane's group, rotated by its owner (see k_linear_lanes) */
 #pragma unroll
@@ -2157,7 +2160,7 @@ __global__ void __launch_bounds__(DPX_ALANES_THREADS) k_affine_lanes(const dpx_f
         constexpr int K = decltype(kTag)::value; /* t & 7 */
         const int tms = t - skew;
         const int rc = rcN;
-        rcN = rp[t + 1];
+        rcN = rp[min(t + 1, rpLast)];
         const int shH = wave_shr1(st.Hoe[R - 1], 0), shD = wave_shr1(st.DeLast, 0);
         const int upHoe = (l == 0) ? bordOe : shH;          /* row-0 border H[0][j] = o + j*e (:50-53) */
         const int upDe = (l == 0) ? (DPX_NEG + e) : shD;    /* virtual D[0][j] */

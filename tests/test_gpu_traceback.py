@@ -76,8 +76,8 @@ def test_banded_traceback_vs_oracle(gpu):
 @pytest.mark.parametrize("algo", ["LSW", "LNW"])
 def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
     """Three ways to walk (DPX_TB_WALK forces one): 0 = one lane per pair, cell by cell; 1 = one lane per pair through register-
-    cached 8-row column vectors; 2 = one wave per pair with an LDS window of 32 rows x 64 columns (the default where the layout
-    has 8-row vectors).  8- and 16-row tiles, several stripes, lane-group, stripe and window crossings, the lane-packed tile
+    cached 8-row column vectors (chosen for batches of >= 65536 pairs); 2 = one wave per pair with an LDS window of 32 rows x 64
+    columns (chosen for LSW / LNW batches whose paths are long, m + n >= 1500, on layouts with 8-row vectors; 0 otherwise).  8- and 16-row tiles, several stripes, lane-group, stripe and window crossings, the lane-packed tile
     layout, the split layout (falls back to walk 0), borders reached from both sides, empty sequences -- every printed line
     against the oracle."""
     monkeypatch.setenv("DPX_TB_WALK", cached)

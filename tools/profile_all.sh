@@ -11,6 +11,9 @@ ROUND=$1; shift
 WLS=${*:-lsw_10k_1024 lnw_10k_1024 lsw_1k_512 anw_1k_1024 bsw_10k_4096_b128 lnw_100k_short lsw_100k_short anw_100k_short}
 REPO=$(pwd); OUT=$REPO/gpurun_out/profile_$ROUND; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $REPO
+# which clock does this box hold under a VALU load / under a store load (boxes of the pool differ by up to 17 % on the latency-bound kernels)
+[ -x tools/bin/clkprobe ] || hipcc --offload-arch=gfx950 -O2 tools/clkprobe.hip -o tools/bin/clkprobe 2>/dev/null
+[ -x tools/bin/clkprobe ] && tools/bin/clkprobe > $OUT/clkprobe.txt 2>&1
 for WL in $WLS; do
   EXTRA="--no-cpu-baseline"; [ $WL = lsw_10k_1024 ] && EXTRA=""
   python3 bench.py --workload $WL $EXTRA > $OUT/${WL}_bench.json 2> $OUT/${WL}_bench.err || { echo "bench $WL failed"; continue; }
