@@ -85,7 +85,11 @@ struct PoolStats { const char *mode = "malloc"; size_t chunkBytes = 0; }; /* wha
 thread_local PoolStats t_poolStats;
 
 void vmm_release(void *va, const VmmRange &r, size_t mappedBytes) {
-    if (mappedBytes) (void)hipMemUnmap(va, mappedBytes);
+    size_t off = 0;
+    for (const auto &c : r.chunks) { /* every mapping is undone with the range it was made with */
+        if (off + c.second <= mappedBytes) (void)hipMemUnmap((char *)va + off, c.second);
+        off += c.second;
+    }
     for (const auto &c : r.chunks) (void)hipMemRelease(c.first);
     (void)hipMemAddressFree(va, r.bytes);
     (void)hipGetLastError();
