@@ -84,15 +84,32 @@ std::map<void *, VmmRange> g_vmmRanges;
 struct PoolStats { const char *mode = "malloc"; size_t chunkBytes = 0; }; /* what the last pool_alloc of this thread did */
 thread_local PoolStats t_poolStats;
 
+/* Tearing a range down: ROCm 7.2 crashed inside hipMemAddressFree in about half the runs of the pool tests (shopping for a pool
+ * builds and drops candidates next to a live one; native backtrace + call trace: profiles/r03/vmm_address_free_crash.txt), and with
+ * one hipMemUnmap over the whole range the chunks behind the first stayed allocated.  What holds: wait for the device, undo every
+ * mapping with the range it was made with, release the handles, wait again, free the address range -- ten of ten runs clean,
+ * tools/pool_leak.py gets every byte back. */
 void vmm_release(void *va, const VmmRange &r, size_t mappedBytes) {
-    size_t off = 0;
-    for (const auto &c : r.chunks) { /* every mapping is undone with the range it was made with */
-        if (off + c.second <= mappedBytes) (void)hipMemUnmap((char *)va + off, c.second);
-        off += c.second;
+    static const bool dbg = getenv("DPX_TRACE_VMM") != nullptr;
+    if (dbg) { fprintf(stderr, "[vmm] release %p bytes %zu mapped %zu chunks %zu: unmap\n", va, r.bytes, mappedBytes, r.chunks.size()); fflush(stderr); }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (r.device >= 0 && r.device != cur) (void)hipSetDevice(r.device); /* (one process may drive several devices: wait for the range's own) */
+    (void)hipDeviceSynchronize();
+    { /* every mapping is undone with the range it was made with */
+        size_t off = 0;
+        for (const auto &c : r.chunks) {
+            if (off + c.second <= mappedBytes) (void)hipMemUnmap((char *)va + off, c.second);
+            off += c.second;
+        }
     }
+    if (dbg) { fprintf(stderr, "[vmm] handles\n"); fflush(stderr); }
     for (const auto &c : r.chunks) (void)hipMemRelease(c.first);
+    (void)hipDeviceSynchronize();
     (void)hipMemAddressFree(va, r.bytes);
+    if (dbg) { fprintf(stderr, "[vmm] done\n"); fflush(stderr); }
     (void)hipGetLastError();
+    if (r.device >= 0 && r.device != cur && cur >= 0) (void)hipSetDevice(cur);
 }
 
 hipError_t pool_alloc(void **out, size_t bytes) {
@@ -133,12 +150,14 @@ hipError_t pool_alloc(void **out, size_t bytes) {
         e = hipMemSetAccess(va, r.bytes, &acc, 1);
     }
     if (e != hipSuccess) {
+        if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] building %p failed after %zu of %zu bytes mapped: %s\n", va, mapped, r.bytes, hipGetErrorString(e)); fflush(stderr); }
         vmm_release(va, r, mapped);
         if (e == hipErrorOutOfMemory) return e;
         /* a runtime without (working) virtual-memory management: one hipMalloc, as before round 3 -- slower to write, never wrong */
         (void)hipGetLastError();
         return hipMalloc(out, bytes);
     }
+    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] alloc %p bytes %zu chunks %zu\n", va, r.bytes, r.chunks.size()); fflush(stderr); }
     { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(va, std::move(r)); }
     t_poolStats.mode = "vmm";
     t_poolStats.chunkBytes = chunk;
@@ -934,7 +953,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
     if (usePacked) {
         dpx_params kp = *params;
         kp.algo = kernelAlgo;
-        usePacked = packed_safe(kp, b->maxM, b->maxN);
+        usePacked = packed_safe(kp, b->maxM, b->maxN) && (!banded || params->gapOpen <= 0); /* (the packed band kernel's gap term saturates at 0) */
         /* 4-byte edge entries + 2-byte reference entries per wave: very long references do not fit the LDS twice over
          * (band kernel: 2-byte query and reference entries) */
         const size_t pkNeed = (banded ? align_up(((size_t)b->maxM + 96) * 2, 16) + align_up(((size_t)b->maxN + 32) * 2, 16)
@@ -1002,7 +1021,8 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
                                   pos(params->gapOpen) * ((long long)b->maxM + b->maxN);
             const size_t edgePk = align_up((size_t)b->maxN + 2, 4); /* uint32 elements */
             const size_t ldsPk = 1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgePk * 4;
-            bool splitPk = numPairs >= 2 && packed_safe(kp, b->maxM, b->maxN) && (kernelAlgo != DPX_ALGO_LSW || top * sR + sR - 1 <= 65535) &&
+            bool splitPk = numPairs >= 2 && packed_safe(kp, b->maxM, b->maxN) &&
+                           (kernelAlgo != DPX_ALGO_LSW || (top * sR + sR - 1 <= 65535 && params->gapOpen <= 0)) &&
                            ldsPk <= 160u * 1024u;
             /* measured (profiles/r03): 1000 x 512^2 0.170 vs 0.118 ms, 500 x 1024^2 +5 %, 2000 / 3000 x 1024^2 -1 % / -3 %: with about one
              * wave per SIMD the fill is bound by the latency of a step, and a packed step is longer -- opt-in (DPX_SPLIT_PK=1) */
@@ -1298,7 +1318,7 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
             auto pos = [](long long v) { return v > 0 ? v : 0; };
             const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
                                   pos(params->gapOpen) * ((long long)b->maxM + b->maxN); /* fits_int16()'s bound on H */
-            k.rowTags = (kernelAlgo == DPX_ALGO_LSW && top * b->R + b->R - 1 <= 65535) ? 1 : 0;
+            k.rowTags = (kernelAlgo == DPX_ALGO_LSW && top * b->R + b->R - 1 <= 65535 && params->gapOpen <= 0) ? 1 : 0; /* (gap <= 0: the saturating gap term) */
             if (const char *env = getenv("DPX_ROW_TAGS")) k.rowTags = (atoi(env) != 0 && k.rowTags) ? 1 : 0; /* A/B runs: 0 = the per-row keys */
         }
     }

@@ -1154,6 +1154,14 @@ __device__ __forceinline__ uint32_t pk_row_tag_of(uint32_t h, const int r) {
 
 __device__ __forceinline__ uint32_t pk_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); } /* {lo.hi16, hi.hi16} */
 
+/* SW with gap <= 0 (round 3): max(up, left) - |gap| SATURATING at 0 (v_pk_sub_u16 ... clamp; SW cells are never negative, so the signed
+ * maximum of two of them is their unsigned one).  The gap term is then >= 0, so H = max(gap term, diag + s) >= 0 without the extra
+ * v_pk_max_i16(H, 0) of c++/LinearSmithWaterman.cpp:103 -- the SW cell costs what the NW cell costs.  The host sends a batch to the
+ * kernels that use this only if gap <= 0. */
+__device__ __forceinline__ s16x2 pk_gap_sat(const uint32_t up, const uint32_t left, const uint32_t gabsP) {
+    return as_s16x2(as_u32(__builtin_elementwise_sub_sat(as_u16x2(as_u32(dpx::pk_max(as_s16x2(up), as_s16x2(left)))), as_u16x2(gabsP))));
+}
+
 template <int R>
 __device__ __forceinline__ void store_tile_pk(int16_t *dstA, int16_t *dstB, const uint32_t (&v)[R]) {
     /* pair A = high halves, pair B = low halves; R/2 dwords each */
@@ -1199,9 +1207,14 @@ __device__ __forceinline__ void pk_step(PkState<R> &st, const int t, const int l
             const uint32_t left = st.Hl[r];
             const uint32_t differs = dpx::pk_min_u16_raw(st.qc[r] ^ rcP, onesP);                 /* 0 / 1 per half */
             const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));         /* match or mismatch per half */
-            const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP);
-            s16x2 h = dpx::pk_max(g, (s16x2)(as_s16x2(d) + sc));
-            if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+            s16x2 h;
+            if constexpr (LOCAL && TAGS) { /* (rowTags batches have gap <= 0: gapP holds |gap| here) */
+                h = dpx::pk_max(pk_gap_sat(u, left, gapP), (s16x2)(as_s16x2(d) + sc));
+            } else {
+                const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP);
+                h = dpx::pk_max(g, (s16x2)(as_s16x2(d) + sc));
+                if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+            }
             d = left;
             u = as_u32(h);
             st.Hl[r] = u;
@@ -1254,7 +1267,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS, DPX_PK_MIN_BLOCKS) k_linear_
     const int gap = a.gapOpen;
     const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
     const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
-    const uint32_t gapP = ((uint32_t)(uint16_t)gap << 16) | (uint16_t)gap;
+    const int gapK = (LOCAL && TAGS) ? -gap : gap; /* row-tag batches (gap <= 0): the cell update subtracts |gap| with saturation (pk_gap_sat) */
+    const uint32_t gapP = ((uint32_t)(uint16_t)gapK << 16) | (uint16_t)gapK;
 
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
     uint32_t *edge = reinterpret_cast<uint32_t *>(my);                    /* packed edge[j], j = 0..n+1 */
@@ -1408,7 +1422,8 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
     const int gap = a.gapOpen;
     const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
     const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
-    const uint32_t gapP = ((uint32_t)(uint16_t)gap << 16) | (uint16_t)gap;
+    const int gapK = LOCAL ? -gap : gap; /* SW (gap <= 0, checked by the host): |gap| for the saturating gap term (pk_gap_sat) */
+    const uint32_t gapP = ((uint32_t)(uint16_t)gapK << 16) | (uint16_t)gapK;
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
 
@@ -1502,9 +1517,9 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
             }
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(Hl[r])) + as_s16x2(gapP);
-                s16x2 h = dpx::pk_max(g, as_s16x2(dsum[r]));
-                if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+                s16x2 h;
+                if constexpr (LOCAL) h = dpx::pk_max(pk_gap_sat(u, Hl[r], gapP), as_s16x2(dsum[r])); /* gap <= 0 (host): gapP = |gap|, no max(H, 0) needed */
+                else h = dpx::pk_max(dpx::pk_max(as_s16x2(u), as_s16x2(Hl[r])) + as_s16x2(gapP), as_s16x2(dsum[r]));
                 u = as_u32(h);
                 Hl[r] = u;
                 if constexpr (LOCAL) {
@@ -1612,9 +1627,9 @@ __device__ __forceinline__ void split_pk_cells(SplitPkState<R> &st, const uint32
         const uint32_t left = st.Hl[r];
         const uint32_t differs = dpx::pk_min_u16_raw(st.qc[r] ^ rcP, onesP);
         const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));
-        const s16x2 g = dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP);
-        s16x2 h = dpx::pk_max(g, (s16x2)(as_s16x2(d) + sc));
-        if constexpr (LOCAL) h = dpx::pk_max(h, as_s16x2(0u));
+        s16x2 h;
+        if constexpr (LOCAL) h = dpx::pk_max(pk_gap_sat(u, left, gapP), (s16x2)(as_s16x2(d) + sc)); /* gap <= 0 (host): gapP = |gap| */
+        else h = dpx::pk_max(dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP), (s16x2)(as_s16x2(d) + sc));
         d = left;
         u = as_u32(h);
         st.Hl[r] = u;
@@ -1646,7 +1661,8 @@ __global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split_pk(co
     const int gap = a.gapOpen;
     const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
     const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
-    const uint32_t gapP = ((uint32_t)(uint16_t)gap << 16) | (uint16_t)gap;
+    const int gapK = LOCAL ? -gap : gap; /* SW (gap <= 0, checked by the host): |gap| for the saturating gap term */
+    const uint32_t gapP = ((uint32_t)(uint16_t)gapK << 16) | (uint16_t)gapK;
     const int W = dpx_tiled_stripes(m, R);
     const unsigned char *refA = reinterpret_cast<const unsigned char *>(a.seq + prA.refIdx);
     const unsigned char *refB = reinterpret_cast<const unsigned char *>(a.seq + prB.refIdx);
@@ -2439,8 +2455,7 @@ __device__ __forceinline__ void band_step_pk(BandStatePk<C> &st, const int A, in
     for (int c = 0; c < C; c++) {
         const uint32_t differs = dpx::pk_min_u16_raw(st.qch[c] ^ st.rch[c], onesP);
         const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));
-        const s16x2 g = dpx::pk_max(as_s16x2(up[c]), as_s16x2(left[c])) + as_s16x2(gapP);
-        uint32_t h = as_u32(dpx::pk_max(dpx::pk_max(g, (s16x2)(as_s16x2(st.prev2[c]) + sc)), as_s16x2(0u)));
+        uint32_t h = as_u32(dpx::pk_max(pk_gap_sat(up[c], left[c], gapP), (s16x2)(as_s16x2(st.prev2[c]) + sc))); /* gap <= 0 (host): gapP = |gap| */
         if constexpr (INTERIOR) {
             h &= st.inBand[P1 ? 1 : 0][c];
         } else {
@@ -2469,7 +2484,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill_pk(const dpx_f
     const int n = prA.n, m = prA.m, B = a.band; /* host guarantees equal shapes, both > 0 */
     const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
     const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
-    const uint32_t gapP = ((uint32_t)(uint16_t)a.gapOpen << 16) | (uint16_t)a.gapOpen;
+    const uint32_t gapP = ((uint32_t)(uint16_t)(-a.gapOpen) << 16) | (uint16_t)(-a.gapOpen); /* |gap| (gap <= 0, checked by the host): pk_gap_sat */
     const unsigned char *refA = reinterpret_cast<const unsigned char *>(a.seq + prA.refIdx), *refB = reinterpret_cast<const unsigned char *>(a.seq + prB.refIdx);
     const unsigned char *qryA = reinterpret_cast<const unsigned char *>(a.seq + prA.qryIdx), *qryB = reinterpret_cast<const unsigned char *>(a.seq + prB.qryIdx);
     unsigned char *my = smem + (size_t)wv * a.ldsPerWave;

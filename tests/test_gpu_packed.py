@@ -171,6 +171,7 @@ def test_row_tag_keys_and_their_limit(gpu, monkeypatch):
         (_uniform(rng, 6, 1000, 900, acgt), (3, -1, -2), 1),
         (_uniform(rng, 6, 700, 900, acgt), (3, 5, 4), 0),              # positive gap: the score bound (9900 * 16) leaves the tag range
         (_uniform(rng, 6, 77, 1500, np.array([0, 255], np.uint8)), (1, 0, 0), 1),   # many equal scores: smallest row, then smallest column
+        (_uniform(rng, 6, 100, 120, acgt), (3, -1, 1), 0),             # the tags would fit, but gap > 0: the tagged kernel's gap term saturates at 0
     ]
     for sb, w, want_tags in cases:
         with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *w) as b:
