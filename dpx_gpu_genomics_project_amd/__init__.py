@@ -28,6 +28,7 @@ from .capi import (  # noqa: F401
     init,
     lib_path,
     load,
+    pack2,
     prim_eval,
 )
 from .synth import SynthBatch, make_batch, parse_pairs_file, write_pairs_file  # noqa: F401
@@ -35,5 +36,5 @@ from .synth import SynthBatch, make_batch, parse_pairs_file, write_pairs_file  #
 __all__ = [
     "ALGO_ANW", "ALGO_BSW", "ALGO_LNW", "ALGO_LSW", "ALGO_NAMES", "MAT_D", "MAT_H", "MAT_I", "SCORE_ONLY", "TIME_FILLS", "TUNE_PLACEMENT",
     "KEEP_MATRICES", "Batch", "DpxError", "Params", "SeqPair", "device_count", "device_info", "init",
-    "lib_path", "load", "prim_eval", "SynthBatch", "make_batch", "parse_pairs_file", "write_pairs_file",
+    "lib_path", "load", "pack2", "prim_eval", "SynthBatch", "make_batch", "parse_pairs_file", "write_pairs_file",
 ]

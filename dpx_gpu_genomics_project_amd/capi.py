@@ -21,7 +21,7 @@ ABI_VERSION_NEEDED = 3  # include/dpx_align.h DPX_ABI_VERSION: round-3 entry poi
 
 ABI_SYMBOLS = (
     "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_pool_reserve", "dpx_strerror", "dpx_last_error",
-    "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_last_output_usec", "dpx_batch_sync",
+    "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_pack2", "dpx_batch_create_packed2", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_last_output_usec", "dpx_batch_sync",
     "dpx_batch_device_results", "dpx_batch_results", "dpx_batch_matrix", "dpx_batch_traceback",
     "dpx_batch_output_begin", "dpx_batch_output_end", "dpx_batch_output_take", "dpx_text_free",
     "dpx_batch_info", "dpx_batch_describe", "dpx_batch_destroy", "dpx_align_batch", "dpx_prim_eval",
@@ -76,6 +76,9 @@ def load() -> C.CDLL:
                                      C.POINTER(vp)]
     lib.dpx_batch_create_on.argtypes = [C.c_int, C.POINTER(Params), vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint,
                                         C.POINTER(vp)]
+    lib.dpx_pack2.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp]
+    lib.dpx_batch_create_packed2.argtypes = [C.c_int, C.POINTER(Params), vp, C.c_size_t, vp, vp, C.c_size_t, C.c_size_t, C.c_uint,
+                                             C.POINTER(vp)]
     lib.dpx_batch_fill.argtypes = [vp, vp]
     lib.dpx_batch_fill_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.dpx_batch_last_fill_usec.argtypes = [vp, C.POINTER(C.c_double)]
@@ -128,22 +131,42 @@ def device_info() -> Tuple[str, int, int]:
     return name.value.decode(), cus.value, mem.value
 
 
+def pack2(sequences: np.ndarray, pairs: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """dpx_pack2 (host only, no GPU): (packed uint8[(n+3)//4], alphabet uint8[4]) of a flat byte buffer whose pairs use at most four
+    byte values; DpxError(-8) otherwise."""
+    lib = load()
+    seq = np.ascontiguousarray(sequences, dtype=np.uint8)
+    prs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    packed = np.zeros((seq.size + 3) // 4, np.uint8)
+    alphabet = np.zeros(4, np.uint8)
+    _check(lib.dpx_pack2(seq.ctypes.data, seq.size, prs.ctypes.data, len(prs), alphabet.ctypes.data, packed.ctypes.data), "dpx_pack2")
+    return packed, alphabet
+
+
 class Batch:
-    """A device-resident batch of alignment pairs (dpx_batch)."""
+    """A device-resident batch of alignment pairs (dpx_batch).  `packed2=(packed, alphabet, num_bases)`: the sequences arrive as 2-bit
+    codes (dpx_batch_create_packed2) and `sequences` is ignored."""
 
     def __init__(self, algo: int, sequences: np.ndarray, pairs: np.ndarray, match: int = 3, mismatch: int = -1,
                  gap_open: int = -2, gap_extend: int = -1, band: int = 0, flags: int = KEEP_MATRICES,
-                 first_pair: int = 0, num_pairs: Optional[int] = None, device: int = -1):
+                 first_pair: int = 0, num_pairs: Optional[int] = None, device: int = -1, packed2=None):
         lib = load()
         self._lib = lib
         self._h = C.c_void_p(None)
-        seq = np.ascontiguousarray(sequences, dtype=np.uint8)
+        seq = np.ascontiguousarray(sequences if sequences is not None else np.zeros(0, np.uint8), dtype=np.uint8)
         prs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
         if num_pairs is None:
             num_pairs = len(prs) - first_pair
         self.params = Params(algo, match, mismatch, gap_open, gap_extend, band)
         self.pairs = prs[first_pair:first_pair + num_pairs].copy()
         self.num_pairs = num_pairs
+        if packed2 is not None:
+            pk = np.ascontiguousarray(packed2[0], dtype=np.uint8)
+            al = np.ascontiguousarray(packed2[1], dtype=np.uint8)
+            rc = lib.dpx_batch_create_packed2(device, C.byref(self.params), pk.ctypes.data, int(packed2[2]), al.ctypes.data, prs.ctypes.data,
+                                              first_pair, num_pairs, flags, C.byref(self._h))
+            _check(rc, "dpx_batch_create_packed2")
+            return
         rc = lib.dpx_batch_create_on(device, C.byref(self.params), seq.ctypes.data, seq.size, prs.ctypes.data, first_pair,
                                      num_pairs, flags, C.byref(self._h))
         _check(rc, "dpx_batch_create")

@@ -393,6 +393,7 @@ struct dpx_batch {
     size_t streamLds = 0;
     bool packed = false;
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
+    bool packed2 = false;  /* the sequences arrived as 2-bit codes (dpx_batch_create_packed2) */
     bool lanesPk = false;  /* lane-packed batch on k_linear_lanes_pk (two row blocks of a pair in the halves of every register) */
     bool splitPk = false;  /* ... two equal-shaped pairs per workgroup on the packed-int16 pipe (k_linear_split_pk); leftovers on k_linear_split */
     size_t splitPkLds = 0;
@@ -754,8 +755,63 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
     return dpx_batch_create_on(-1, params, sequences, numBytes, pairs, firstPair, numPairs, flags, out);
 }
 
+/* `alphabet` == nullptr: `sequences` are numBytes plain bytes.  Otherwise `sequences` holds numBytes BASES, four per byte (base k in
+ * bits 2*(k%4) of byte k/4), alphabet[code] is the byte a code stands for, and the pairs' indices count bases. */
+static int create_impl(int device, const dpx_params *params, const char *sequences, size_t numBytes, const uint8_t *alphabet,
+                       const dpx_seq_pair *pairs, size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
+
 int dpx_batch_create_on(int device, const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
                         size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
+    return create_impl(device, params, sequences, numBytes, nullptr, pairs, firstPair, numPairs, flags, out);
+}
+
+int dpx_batch_create_packed2(int device, const dpx_params *params, const uint8_t *packed, size_t numBases, const uint8_t alphabet[4],
+                             const dpx_seq_pair *pairs, size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
+    if (!alphabet) return DPX_ERR_INVALID;
+    return create_impl(device, params, reinterpret_cast<const char *>(packed), numBases, alphabet, pairs, firstPair, numPairs, flags, out);
+}
+
+/* Host side of the 2-bit input: the distinct byte values inside the pairs' ranges become the alphabet (in order of first appearance;
+ * more than four: DPX_ERR_UNSUPPORTED, the caller keeps its bytes), every byte of `sequences` its 2-bit code (bytes outside
+ * every pair -- parseInput's separators -- and bytes of other values: code 0, never read).  packed: (numBytes + 3) / 4 bytes. */
+int dpx_pack2(const char *sequences, size_t numBytes, const dpx_seq_pair *pairs, size_t numPairs, uint8_t alphabet[4], uint8_t *packed) {
+    if ((numBytes && !sequences) || (numPairs && !pairs) || !alphabet || (numBytes && !packed)) return DPX_ERR_INVALID;
+    int code[256];
+    for (int &c : code) c = -1;
+    int used = 0;
+    const unsigned char *sq = reinterpret_cast<const unsigned char *>(sequences);
+    for (size_t i = 0; i < numPairs; i++) {
+        const dpx_seq_pair &sp = pairs[i];
+        if (sp.referenceSize < 0 || sp.querySize < 0 || sp.referenceIdx < 0 || sp.queryIdx < 0 ||
+            (size_t)sp.referenceIdx + (size_t)sp.referenceSize > numBytes || (size_t)sp.queryIdx + (size_t)sp.querySize > numBytes)
+            return DPX_ERR_INVALID;
+        for (int side = 0; side < 2; side++) {
+            const unsigned char *p = sq + (side ? sp.queryIdx : sp.referenceIdx);
+            const size_t len = (size_t)(side ? sp.querySize : sp.referenceSize);
+            for (size_t k = 0; k < len; k++) {
+                if (code[p[k]] >= 0) continue;
+                if (used == 4) return DPX_ERR_UNSUPPORTED;
+                alphabet[used] = p[k];
+                code[p[k]] = used++;
+            }
+        }
+    }
+    for (int k = used; k < 4; k++) alphabet[k] = used ? alphabet[0] : (uint8_t)'0';
+    uint8_t lut[256];
+    for (int v = 0; v < 256; v++) lut[v] = (uint8_t)(code[v] < 0 ? 0 : code[v]);
+    const size_t whole = numBytes / 4;
+    for (size_t q = 0; q < whole; q++)
+        packed[q] = (uint8_t)(lut[sq[4 * q]] | (lut[sq[4 * q + 1]] << 2) | (lut[sq[4 * q + 2]] << 4) | (lut[sq[4 * q + 3]] << 6));
+    if (numBytes & 3) {
+        uint8_t v = 0;
+        for (size_t k = 4 * whole; k < numBytes; k++) v = (uint8_t)(v | (lut[sq[k]] << (2 * (k & 3))));
+        packed[whole] = v;
+    }
+    return DPX_OK;
+}
+
+static int create_impl(int device, const dpx_params *params, const char *sequences, size_t numBytes, const uint8_t *alphabet,
+                       const dpx_seq_pair *pairs, size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out) {
     if (!out) return DPX_ERR_INVALID;
     *out = nullptr;
     int rc = validate_params(params);
@@ -1068,16 +1124,22 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         seqHi = std::max(seqHi, std::max((size_t)pd.refIdx + (size_t)pd.n, (size_t)pd.qryIdx + (size_t)pd.m));
     }
     if (seqHi <= seqLo) seqLo = seqHi = 0;
+    if (alphabet) seqLo &= ~(size_t)15; /* 2-bit input: the device expands whole dwords of 16 bases */
     for (size_t i = 0; i < numPairs; i++) { b->pairs[i].refIdx -= (int32_t)seqLo; b->pairs[i].qryIdx -= (int32_t)seqLo; }
-    sequences += seqLo;
+    const size_t packedTotal = alphabet ? (numBytes + 3) / 4 : 0; /* bytes of the caller's packed buffer */
+    sequences += alphabet ? seqLo / 4 : seqLo;
     numBytes = seqHi - seqLo;
+    const size_t packedDwords = alphabet ? (numBytes + 15) / 16 : 0;
+    const size_t packedCopy = alphabet ? std::min(packedDwords * 4, packedTotal - std::min(packedTotal, seqLo / 4)) : 0;
+    char *dPacked = nullptr;
     {
         const size_t np1 = std::max<size_t>(numPairs, 1);
-        const size_t szSeq = align_up(std::max<size_t>(numBytes, 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
+        const size_t szSeq = align_up(std::max<size_t>(std::max(numBytes, packedDwords * 16), 16), 256), szPairs = align_up(np1 * sizeof(dpx_pair_dev), 256);
+        const size_t szPacked = alphabet ? align_up(std::max<size_t>(packedDwords * 4, 16), 256) : 0;
         const size_t szI32 = align_up(np1 * sizeof(int32_t), 256), szOff = align_up((np1 + 1) * sizeof(uint64_t), 256);
         const size_t szCouples = std::max(szI32, align_up(waves.size() * sizeof(dpx_wave_desc), 256)); /* couples, or the wave descriptors */
         const size_t szScan = align_up((dpx_out_scan_tiles(np1) + 1) * sizeof(uint64_t), 256);
-        const size_t need = szSeq + szPairs + 5 * szI32 + szCouples + 2 * szOff + szScan; /* score, endRow, endCol, order, couples, tbLen; tbOff, outOff, scan */
+        const size_t need = szSeq + szPairs + 5 * szI32 + szCouples + 2 * szOff + szScan + szPacked; /* score, endRow, endCol, order, couples, tbLen; tbOff, outOff, scan; 2-bit staging */
         CREATE_TRY(g_arenaCache.take((void **)&b->arena, need, &b->arenaCap));
         char *q = b->arena;
         b->dSeq = q;                  q += szSeq;
@@ -1090,10 +1152,17 @@ int dpx_batch_create_on(int device, const dpx_params *params, const char *sequen
         b->dTbLen = (int32_t *)q;     q += szI32;
         b->dTbOff = (uint64_t *)q;    q += szOff;
         b->dOutOff = (uint64_t *)q;   q += szOff;
-        b->dOutScratch = (uint64_t *)q;
+        b->dOutScratch = (uint64_t *)q; q += szScan;
+        dPacked = alphabet ? q : nullptr;
     }
     trace.mark("create: arena");
-    if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
+    if (alphabet) { /* a quarter of the bytes over PCIe, expanded by k_unpack2 into the byte buffer the kernels read */
+        if (packedCopy) CREATE_TRY(hipMemcpy(dPacked, sequences, packedCopy, hipMemcpyHostToDevice));
+        const uint32_t alpha = (uint32_t)alphabet[0] | ((uint32_t)alphabet[1] << 8) | ((uint32_t)alphabet[2] << 16) | ((uint32_t)alphabet[3] << 24);
+        CREATE_TRY(dpx_launch_unpack2(reinterpret_cast<const uint32_t *>(dPacked), alpha, b->dSeq, packedDwords, b->stream));
+        CREATE_TRY(hipStreamSynchronize(b->stream)); /* (a fill may run on a caller's stream) */
+        b->packed2 = true;
+    } else if (numBytes) CREATE_TRY(hipMemcpy(b->dSeq, sequences, numBytes, hipMemcpyHostToDevice));
     trace.mark("create: H2D sequences");
     if (b->lanePacked) {
         b->dCouples = arenaCouples;
@@ -1709,9 +1778,9 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
                          : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
-    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d",
+    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d seq_input=%s",
                        names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
-                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags);
+                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes");
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;
         len += snprintf(buf + len, cap - (size_t)len, " pool=%s pool_bytes=%zu pool_chunk_mb=%zu pool_kept=%d pool_memset_ms=", r.mode.c_str(), b->matPoolBytes,

@@ -63,6 +63,7 @@ size_t dpx_out_scan_tiles(size_t numPairs);
 hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff, const char *tb,
                              int numPairs, unsigned long long firstNumber, unsigned long long *tileSums, unsigned long long *outOff, char *out,
                              bool scanOnly, bool compactOnly, hipStream_t stream);
+hipError_t dpx_launch_unpack2(const uint32_t *packed, uint32_t alphabet, char *out, size_t numDwords, hipStream_t stream);
 hipError_t dpx_launch_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
                                 uint32_t *res, uint32_t *pred, hipStream_t stream);
 

@@ -3095,6 +3095,26 @@ __global__ void __launch_bounds__(256) k_out_compact(const dpx_pair_dev *pairs, 
 }
 
 /* =====================================================================================================
+ * 2-bit packed input (dpx_batch_create_packed2; the input side of c++/parseInput.cpp:78-112): the host sends four bases
+ * per byte (base k in bits 2*(k%4) of byte k/4) and a 4-entry alphabet; one thread expands one dword = 16 bases into the 16 bytes
+ * of the byte buffer that every fill, traceback and output kernel reads (one aligned 16-byte store).  The fills keep matching
+ * plain bytes (the reference's contract: any alphabet), so a packed batch and a byte batch are the same batch after this kernel.
+ * ===================================================================================================== */
+__global__ void __launch_bounds__(256) k_unpack2(const uint32_t *packed, const uint32_t alphabet, uint4 *out, const size_t numDwords) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= numDwords) return;
+    const uint32_t w = packed[i];
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { /* eight bits of w = four bases = one output dword: v_perm_b32 picks alphabet bytes by selector */
+        const uint32_t c = (w >> (8 * k)) & 0xFFu;
+        const uint32_t sel = (c & 3u) | (((c >> 2) & 3u) << 8) | (((c >> 4) & 3u) << 16) | ((c >> 6) << 24);
+        o[k] = __builtin_amdgcn_perm(0u, alphabet, sel);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+/* =====================================================================================================
  * DPX primitive probe (dpx_prim_eval): runs the CDNA4 mappings of dpx_prims.hpp on the device.
  * ===================================================================================================== */
 __global__ void k_prim_eval(const int32_t *op, const uint32_t *a, const uint32_t *b, const uint32_t *c, size_t count,
@@ -3407,6 +3427,13 @@ hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, co
     if (!scanOnly)
         hipLaunchKernelGGL(k_out_compact, dim3((unsigned)((numPairs + 3) / 4)), dim3(256), 0, stream, pairs, score, tbLen, tbOff, tb, numPairs, firstNumber,
                            outOff, out);
+    return hipGetLastError();
+}
+
+/* expand numDwords x 16 bases (2 bits each) into bytes: out must be 16-byte aligned and hold 16 * numDwords bytes */
+hipError_t dpx_launch_unpack2(const uint32_t *packed, uint32_t alphabet, char *out, size_t numDwords, hipStream_t stream) {
+    if (numDwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((numDwords + 255) / 256)), dim3(256), 0, stream, packed, alphabet, reinterpret_cast<uint4 *>(out), numDwords);
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-pack2] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
@@ -55,7 +55,7 @@ int main(int argc, char *argv[]) {
     int match = 3, mismatch = -1, gapOpen = -2, gapExtend = -1, band = 128, device = 0, rank = 0, world = 1;
     size_t batchSize = 0;     // 0: from the pool budget (the reference's BATCH_SIZE, V19.cu:9, assumes short reads)
     double poolGb = 4.0;
-    bool print = true;
+    bool print = true, pack2 = false;
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -73,6 +73,7 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-pool-gb")) poolGb = atof(next("-pool-gb"));
         else if (!strcmp(argv[i], "-device")) device = atoi(next("-device"));
         else if (!strcmp(argv[i], "-noprint")) print = false;
+        else if (!strcmp(argv[i], "-pack2")) pack2 = true;
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
@@ -121,6 +122,16 @@ int main(int argc, char *argv[]) {
         const double fit = (double)poolBudget / (perPair > 0 ? perPair : 1);
         batchSize = (size_t)std::min(20000.0, std::max(64.0, fit));
     }
+    // -pack2: the parse step emits four bases per byte (alphabets of up to four symbols); the batches then move a quarter of the
+    // sequence bytes to the device, which expands them (dpx_batch_create_packed2).  Like parsing, outside the timer.
+    std::vector<uint8_t> packed;
+    uint8_t alphabet[4] = {0, 0, 0, 0};
+    if (pack2) {
+        packed.resize((fileInfo.numBytes + 3) / 4 + 1);
+        rc = dpx_pack2(sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), fileInfo.numPairs, alphabet, packed.data());
+        if (rc == DPX_ERR_UNSUPPORTED) { fprintf(stderr, "-pack2: more than four distinct symbols, keeping bytes\n"); pack2 = false; }
+        else if (rc != DPX_OK) die("FAILED TO PACK THE SEQUENCES", rc);
+    }
     if (reserve.joinable()) reserve.join();
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
@@ -167,8 +178,10 @@ int main(int argc, char *argv[]) {
         next.first = first;
         next.count = std::min(batchSize, shardHi - first);
         uint64_t t0 = get_time();
-        rc = dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
-                              DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
+        rc = pack2 ? dpx_batch_create_packed2(-1, &prm, packed.data(), fileInfo.numBytes, alphabet, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs),
+                                              first, next.count, DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b)
+                   : dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
+                                      DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
         if (rc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", rc);
         memalloc_time += get_time() - t0;
         if ((rc = dpx_batch_fill(next.b, nullptr)) != DPX_OK) die("KERNEL LAUNCH FAILED", rc);

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* 1: round 1.  2: + dpx_batch_create_on, dpx_batch_fill_timed, dpx_batch_last_fill_usec, dpx_batch_output_begin/_end/_take,
- * dpx_text_free, DPX_TUNE_PLACEMENT (round 2).  3: + dpx_pool_reserve, dpx_batch_last_output_usec; dpx_batch_describe reports the
+ * dpx_text_free, DPX_TUNE_PLACEMENT (round 2).  3: + dpx_pool_reserve, dpx_batch_last_output_usec, dpx_pack2, dpx_batch_create_packed2; dpx_batch_describe reports the
  * matrix pool (round 3).  Additions only: a caller built against an older version keeps working; dpx_abi_version() >= the version
  * a caller needs is the check. */
 #define DPX_ABI_VERSION 3
@@ -118,6 +118,20 @@ int dpx_batch_create(const dpx_params *params, const char *sequences, size_t num
  * the layout of the batched driver and of bench.py.  device >= count is DPX_ERR_INVALID. */
 int dpx_batch_create_on(int device, const dpx_params *params, const char *sequences, size_t numBytes, const dpx_seq_pair *pairs,
                         size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
+
+/* ---- 2-bit packed input (the input side of c++/parseInput.cpp:78-112) -------------------------------------------
+ * The reference keeps one byte per base.  A caller whose sequences use at most four distinct byte values (DNA: "ACGT", the
+ * reference's datasets: "0123") may hand the engine four bases per byte: base k sits in bits 2*(k%4) of byte k/4, alphabet[code] is
+ * the byte a code stands for, and the pairs keep the reference's struct seqPair -- their indices count bases of the packed buffer
+ * exactly as they counted bytes of the flat one.  The engine moves a quarter of the bytes over PCIe and expands them on the device
+ * (k_unpack2) into the byte buffer that the fill, traceback and output kernels read: results, matrices and printed text are
+ * those of the byte batch.  dpx_pack2() is the host side: it derives the alphabet from the bytes inside the pairs' ranges (order of
+ * first appearance) and packs `sequences` (bytes outside every pair, e.g. parseInput's separators, become code 0);
+ * DPX_ERR_UNSUPPORTED when the pairs use more than four byte values (the caller keeps dpx_batch_create).  `packed` must hold
+ * (numBytes + 3) / 4 bytes. */
+int dpx_pack2(const char *sequences, size_t numBytes, const dpx_seq_pair *pairs, size_t numPairs, uint8_t alphabet[4], uint8_t *packed);
+int dpx_batch_create_packed2(int device, const dpx_params *params, const uint8_t *packed, size_t numBases, const uint8_t alphabet[4],
+                             const dpx_seq_pair *pairs, size_t firstPair, size_t numPairs, unsigned flags, dpx_batch **out);
 
 /* Launch the DP fill for every pair of the batch on `stream` (a hipStream_t, or NULL for the batch's own
  * stream).  Asynchronous.  Replaces `needleman_wunsch_kernel<<<BATCH/2,32,smem>>>` (V19.cu:536),

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "dpx_align.h")).read()
-    declared = set(re.findall(r"\b(dpx_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(capi.ABI_SYMBOLS), declared ^ set(capi.ABI_SYMBOLS)
     lib = dpx.load()
     for name in declared:
@@ -129,3 +129,29 @@ def test_cpp_loaders_agree_with_the_file_format(tmp_path):
     open(bad, "wb").write(b"0\nACGT\n")
     r = subprocess.run([tool, bad, "0", "2"], capture_output=True, text=True)
     assert r.returncode == 1 and "multiple of 3" in r.stderr      # same failure mode as parseInput.cpp:38-41
+
+
+def test_pack2_is_the_two_bit_image_of_the_pairs_bytes():
+    """dpx_pack2 (host side of the 2-bit input, no GPU involved): base k sits in bits 2*(k%4) of byte k/4 and alphabet[code] gives the
+    byte back for every position inside a pair; separators and pair numbers (outside every pair) are don't-cares; a fifth symbol
+    inside a pair is refused (the caller keeps its bytes)."""
+    for sb in (make_ragged_batch(40, 0, 50, 0, 70, seed=9), from_strings([("GATTACA", "GCATGCT"), ("", "ACGT"), ("T", "")]),
+               from_strings([("", "")])):
+        packed, alphabet = dpx.pack2(sb.sequences, sb.pairs)
+        assert packed.size == (sb.sequences.size + 3) // 4 and alphabet.size == 4
+        codes = np.stack([(packed >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[:sb.sequences.size]
+        back = alphabet[codes]
+        for p in sb.pairs:
+            for i, n in ((p["referenceIdx"], p["referenceSize"]), (p["queryIdx"], p["querySize"])):
+                assert np.array_equal(back[i:i + n], sb.sequences[i:i + n])
+    packed, alphabet = dpx.pack2(*(lambda b: (b.sequences, b.pairs))(from_strings([("GATTACA", "GCATGCT")])))
+    assert bytes(alphabet) == b"GATC"  # order of first appearance, reference first
+    with pytest.raises(dpx.DpxError) as e:
+        five = from_strings([("ACGT", "ACGTN")])
+        dpx.pack2(five.sequences, five.pairs)
+    assert e.value.status == -8
+    bad = from_strings([("ACGT", "ACGT")])
+    bad.pairs["referenceSize"][0] = 10_000
+    with pytest.raises(dpx.DpxError) as e:
+        dpx.pack2(bad.sequences, bad.pairs)
+    assert e.value.status == -1 or e.value.status < 0
