@@ -472,17 +472,32 @@ int dpx_init(int device) {
         /* One-time costs of the HIP runtime belong to device initialisation (the reference's mains likewise create their
          * context and query the device before they start their timer, cuda/LNW/LinearNeedlemanWunschV19.cu:357-409):
          * the first hipStreamCreate costs ~9 ms, the first pageable H2D / D2H another ~9 ms (runtime staging buffers).
-         * Two streams go to the stream cache, and a small copy runs in each direction. */
+         * Two streams go to the stream cache, and a small copy runs in each direction.  The first ASYNCHRONOUS copy into pinned host
+         * memory on a stream costs another ~18 ms (round 3, DPX_TRACE of dpx_main: "output: D2H text 18.7 ms" for the first batch's
+         * 5 MB, 0.3 ms for every later one): one such copy of 4 MiB runs here, in both directions, on both parked streams. */
         hipStream_t s0 = nullptr, s1 = nullptr;
-        if (hipStreamCreateWithFlags(&s0, hipStreamNonBlocking) == hipSuccess) stream_park(s0);
-        if (hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess) stream_park(s1);
+        const bool have0 = hipStreamCreateWithFlags(&s0, hipStreamNonBlocking) == hipSuccess;
+        const bool have1 = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess;
         void *d = nullptr;
         std::vector<char> h((size_t)1 << 20, 0);
-        if (hipMalloc(&d, h.size()) == hipSuccess) {
+        const size_t warm = (size_t)4 << 20;
+        if (hipMalloc(&d, warm) == hipSuccess) {
             (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
             (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
+            void *pinned = nullptr;
+            if (hipHostMalloc(&pinned, warm, hipHostMallocDefault) == hipSuccess) {
+                for (hipStream_t s : {have0 ? s0 : nullptr, have1 ? s1 : nullptr}) {
+                    if (!s) continue;
+                    (void)hipMemcpyAsync(pinned, d, warm, hipMemcpyDeviceToHost, s);
+                    (void)hipMemcpyAsync(d, pinned, warm, hipMemcpyHostToDevice, s);
+                    (void)hipStreamSynchronize(s);
+                }
+                (void)hipHostFree(pinned);
+            }
             (void)hipFree(d);
         }
+        if (have0) stream_park(s0);
+        if (have1) stream_park(s1);
         (void)hipGetLastError();
     }
     return DPX_OK;
@@ -1608,6 +1623,12 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
  * already formatted as c++/main.cpp prints them, so a driver writes a batch with one fwrite) */
 
 /* stage 1, asynchronous on the batch's stream: kernels + D2H of the offsets / lengths */
+/* paths at least this long (m + n) are walked by one wave per pair through an LDS window (k_traceback_wave; DPX_TB_WAVE_MIN overrides) */
+static int wave_walk_min_path() {
+    static const int v = [] { const char *e = getenv("DPX_TB_WAVE_MIN"); return e ? std::max(0, atoi(e)) : 1500; }();
+    return v;
+}
+
 static int output_begin(dpx_batch *b, uint64_t firstNumber) {
     PhaseTrace trace;
     const size_t np = b->numPairs;
@@ -1645,8 +1666,7 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         int walk = b->numPairs >= 65536 ? 1 : 0;
         /* long paths on layouts with 8-row column vectors: one wave per pair through an LDS window, one HBM round trip per ~32
          * path steps instead of one per step (round 2: 5000 x 1024^2 LSW 1.60 vs 1.83 ms; loses below ~1000-step paths) */
-        if (b->maxM + b->maxN >= 1500 && b->numPairs < 65536 && !b->split && b->R >= 8 &&
-            (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW)) walk = 2;
+        if (b->maxM + b->maxN >= wave_walk_min_path() && b->numPairs < 65536 && b->kernelAlgo != DPX_ALGO_BSW) walk = 2;
         if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
         else if (const char *env = getenv("DPX_TB_CACHED")) walk = atoi(env) != 0 ? 1 : 0; /* (round-1 knob, tests) */
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));

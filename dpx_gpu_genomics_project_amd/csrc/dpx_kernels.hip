@@ -2860,39 +2860,70 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
 }
 
 /* -----------------------------------------------------------------------------------------------------
- * Wave-cooperative traceback (LSW / LNW on layouts whose 8-row groups are 16 contiguous bytes: rows per lane >= 8).
+ * Wave-cooperative traceback (LSW / LNW / ANW, every matrix layout of the fill kernels).
  * The lane-per-pair walk above pays one dependent HBM round trip per path step (1100 of them on a 1024 x 1024 pair).  Here
  * one WAVE owns a pair: its 64 lanes fetch a window of the matrix around the walker in one go -- 4 row groups (32 rows) x 64
- * columns, four 16-byte loads per lane, plus the query / reference characters of those rows / columns -- into LDS, and the
- * walk (computed by all lanes alike, emitted by lane 0) then runs out of LDS until it leaves the window through its top or its
- * left edge: one HBM round trip per ~32 steps of a diagonal path instead of one per step.
+ * columns of every plane, the 8 rows of a group and column with one 16-byte load (layouts with fewer than 8 rows per lane: 8- or
+ * 4-byte pieces), plus the query / reference characters of those rows / columns -- into LDS, and the walk then runs out of LDS
+ * until it leaves the window through its top or its left edge: one HBM round trip per ~32 steps of a diagonal path instead of
+ * one per step.
+ * Round 3: the walk is SCALAR.  The window is a row-major int16 image per plane (a row is 128 bytes) in which the borders (row
+ * 0, column 0) are ordinary cells, so the neighbours of a step are ds_read_i16 off ONE address, issued together with the two
+ * character reads (one LDS round trip per step, round 2: two to three); everything they return goes through
+ * v_readfirstlane, so position, score, state, the emitted characters and every branch live on the scalar unit (round 2: ~100
+ * vector instructions per step in all 64 lanes).  Lane 0 stores four characters per line every fourth step.
+ * LDS: planes x 4 KiB + the characters (dynamic).
  * ----------------------------------------------------------------------------------------------------- */
-constexpr int kWinGroups = 4, kWinCols = 64;
+constexpr int kWinGroups = 4, kWinCols = 64, kWinRows = 8 * kWinGroups, kWinPlane = kWinRows * kWinCols;
+size_t dpx_traceback_wave_lds(int planes) { return (size_t)planes * kWinPlane * sizeof(int16_t) + kWinRows + 8 + kWinCols + 8; }
 
-__global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int algo, int R, int planes, const int32_t *endRow,
+/* the 8 rows 8*grp+1 .. 8*grp+8 of column jc (>= 1) of `plane`, whatever the layout: one 16-byte piece where a lane owns >= 8 rows
+ * (wavefront-tiled with 8-row sub-tiles, tile layout), otherwise the pieces of 8 / Rr neighbouring lanes (they sit in different chunks) */
+__device__ __forceinline__ u32x4 tb_load_group8(const int16_t *base, const dpx_pair_dev &pr, const int Rr, const int planes, const int plane,
+                                                const int grp, const int jc, const int n) {
+    const int i1 = grp * 8 + 1;
+    if (Rr >= 8) return *reinterpret_cast<const u32x4 *>(base + dpx_cell_index(i1, jc, n, Rr, plane, planes, pr.chunkStride, pr.lanes));
+    if (Rr == 4) {
+        const uint2 lo = *reinterpret_cast<const uint2 *>(base + dpx_cell_index(i1, jc, n, 4, plane, planes, pr.chunkStride, pr.lanes));
+        const uint2 hi = *reinterpret_cast<const uint2 *>(base + dpx_cell_index(i1 + 4, jc, n, 4, plane, planes, pr.chunkStride, pr.lanes));
+        return u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    u32x4 v;
+    v.x = *reinterpret_cast<const uint32_t *>(base + dpx_cell_index(i1, jc, n, 2, plane, planes, pr.chunkStride, pr.lanes));
+    v.y = *reinterpret_cast<const uint32_t *>(base + dpx_cell_index(i1 + 2, jc, n, 2, plane, planes, pr.chunkStride, pr.lanes));
+    v.z = *reinterpret_cast<const uint32_t *>(base + dpx_cell_index(i1 + 4, jc, n, 2, plane, planes, pr.chunkStride, pr.lanes));
+    v.w = *reinterpret_cast<const uint32_t *>(base + dpx_cell_index(i1 + 6, jc, n, 2, plane, planes, pr.chunkStride, pr.lanes));
+    return v;
+}
+
+template <int PLANES>
+__global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int algo, int R, const int32_t *endRow,
                                                        const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
-    __shared__ u32x4 win[kWinGroups][kWinCols];
-    __shared__ unsigned char wq[8 * kWinGroups + 8], wr[kWinCols + 8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemTb[];
+    int16_t *win = reinterpret_cast<int16_t *>(smemTb); /* win[plane * kWinPlane + (ii - R0 - 1) * 64 + (jj - cLo)] = plane[ii][jj] */
+    unsigned char *wq = smemTb + PLANES * kWinPlane * sizeof(int16_t), *wr = wq + kWinRows + 8;
     const int p = blockIdx.x;
     const int lane = threadIdx.x;
     if (p >= numPairs) return;
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
     const int Rr = pr.rows ? (int)pr.rows : R;
-    const bool eligible = (algo == DPX_K_LSW || algo == DPX_K_LNW) && Rr >= 8 && (pr.lanes == 64 || pr.lanes == 16) && m > 0 && n > 0;
-    if (!eligible) { /* other layouts / algorithms: the one-lane walk (wave-uniform branch) */
-        if (lane == 0) tb_walk_lane(a, p, algo, R, planes, 0, endRow, endCol, tbOff, tb, tbLen);
+    const bool eligible = (PLANES == 3 ? algo == DPX_K_ANW : (algo == DPX_K_LSW || algo == DPX_K_LNW)) && (Rr == 2 || Rr == 4 || Rr == 8 || Rr == 16) &&
+                          (pr.lanes == 64 || pr.lanes == 16 || pr.lanes == 32) && m > 0 && n > 0;
+    if (!eligible) { /* banded matrices, empty sequences: the one-lane walk (wave-uniform branch) */
+        if (lane == 0) tb_walk_lane(a, p, algo, R, PLANES, 0, endRow, endCol, tbOff, tb, tbLen);
         return;
     }
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
+    const int16_t *base = a.mat + pr.matOff;
     const int cap = (m + n + 1 + 3) & ~3;
     char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
     int pos = cap;
     uint32_t accR = 0, accX = 0, accQ = 0;
-    const int match = a.match, mismatch = a.mismatch, g = a.gapOpen;
-    const int border = algo == DPX_K_LNW ? g : 0; /* H on row 0 / column 0 is border * (i + j) */
-    TileWalker tw{a.mat, pr.matOff, pr.chunkStride, pr.lanes, n, dpx_log2(Rr), border}; /* (only its column() is used) */
+    const int match = a.match, mismatch = a.mismatch, g = a.gapOpen, ext = a.gapExtend;
+    /* H on row 0 / column 0, `len` cells from the corner (TbView::get): LNW len * gap, ANW open + len * extend (0 in the corner), LSW 0 */
+    auto bval = [&](const int len) -> int { return algo == DPX_K_LNW ? len * g : (algo == DPX_K_ANW ? (len ? g + len * ext : 0) : 0); };
 #define EMITW(rc_, xc_, qc_)                                                                     \
     {                                                                                            \
         --pos;                                                                                   \
@@ -2905,67 +2936,114 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
             *reinterpret_cast<uint32_t *>(lq + pos) = accQ;                                      \
         }                                                                                        \
     }
-    int i = endRow[p], j = endCol[p];
-    int gBase = 0, cLo = 1; /* window: row groups gBase .. gBase+3 (rows 8*gBase+1 ..), columns cLo .. cLo+63 */
-    auto load_window = [&](const int ii, const int jj) { /* anchored so that (ii, jj) is its bottom-right corner region */
-        gBase = ((ii - 1) >> 3) - (kWinGroups - 1);
+    int i = __builtin_amdgcn_readfirstlane(endRow[p]), j = __builtin_amdgcn_readfirstlane(endCol[p]);
+    int R0 = 1 << 28, cLo = 1 << 28; /* window: rows R0+1 .. R0+32 (R0 = 8 * first row group; may be negative), columns cLo .. cLo+63 */
+    auto load_window = [&](const int ii, const int jj) __attribute__((always_inline)) { /* (ii, jj) in its bottom-right corner region */
+        const int gBase = ((ii - 1) >> 3) - (kWinGroups - 1);
+        R0 = gBase * 8;
         cLo = jj - (kWinCols - 1);
         const int jc = cLo + lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the previous window's reads are done before it is overwritten */
         __builtin_amdgcn_wave_barrier();
+        u32x4 v[PLANES][kWinGroups];
 #pragma unroll
-        for (int gi = 0; gi < kWinGroups; gi++) {
-            const int grp = gBase + gi;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v = tw.column(grp * 8, jc);
-            win[gi][lane] = v;
+        for (int pl = 0; pl < PLANES; pl++) {
+#pragma unroll
+            for (int gi = 0; gi < kWinGroups; gi++) { /* the loads first, all in flight together */
+                const int grp = gBase + gi;
+                v[pl][gi] = u32x4{0u, 0u, 0u, 0u};
+                if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = tb_load_group8(base, pr, Rr, PLANES, pl, grp, jc, n);
+            }
         }
-        if (lane < 8 * kWinGroups) { const int qi = gBase * 8 + lane; wq[lane] = (qi >= 0 && qi < m) ? qry[qi] : 0; }
-        wr[lane] = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; pl++) {
+#pragma unroll
+            for (int gi = 0; gi < kWinGroups; gi++) {
+                const int grp = gBase + gi;
+                if (pl == 0 && algo != DPX_K_LSW && (jc == 0 || grp < 0)) { /* the borders of H as cells: column 0 and row 0 (other cells here are never read) */
+                    uint32_t d[4];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const int r0 = grp * 8 + 1 + e, r1 = r0 + 1;
+                        const int v0 = jc == 0 ? (r0 >= 0 ? bval(r0) : 0) : (r0 == 0 && jc > 0 ? bval(jc) : 0);
+                        const int v1 = jc == 0 ? (r1 >= 0 ? bval(r1) : 0) : (r1 == 0 && jc > 0 ? bval(jc) : 0);
+                        d[e >> 1] = ((uint32_t)(uint16_t)v1 << 16) | (uint32_t)(uint16_t)v0;
+                    }
+                    v[pl][gi] = u32x4{d[0], d[1], d[2], d[3]};
+                }
+                int16_t *dst = win + pl * kWinPlane + (gi * 8) * kWinCols + lane;
+                const uint32_t w4[4] = {v[pl][gi].x, v[pl][gi].y, v[pl][gi].z, v[pl][gi].w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) dst[e * kWinCols] = (int16_t)(w4[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        if (lane < kWinRows) { const int qi = R0 + lane; wq[lane] = (qi >= 0 && qi < m) ? qry[qi] : 0; } /* wq[ii - R0 - 1] = query character of row ii */
+        wr[lane] = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0;                                               /* wr[jj - cLo] = reference character of column jj */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto need_window = [&]() -> bool { /* rows i-1, i and columns j-1, j (those >= 1) must lie inside the window */
-        const int rTop = min(i, max(i - 1, 1)), cLeft = min(j, max(j - 1, 1));
-        return (i >= 1 && ((rTop - 1) >> 3) < gBase) || (j >= 1 && cLeft < cLo) || (i >= 1 && ((i - 1) >> 3) > gBase + kWinGroups - 1) ||
-               (j >= 1 && j > cLo + kWinCols - 1);
-    };
-    auto H = [&](const int ii, const int jj) -> int {
-        if (ii == 0 || jj == 0) return border * (ii + jj);
-        const int16_t *w = reinterpret_cast<const int16_t *>(&win[((ii - 1) >> 3) - gBase][jj - cLo]);
-        return (int)w[(ii - 1) & 7];
-    };
-    auto qc_of = [&](const int ii) -> int { return wq[(ii - 1) - gBase * 8]; };  /* query character of row ii */
-    auto rc_of = [&](const int jj) -> int { return wr[jj - cLo]; };              /* reference character of column jj */
-    gBase = 1 << 28; /* no window yet */
+    /* rows i-1, i and columns j-1, j must lie inside the window (borders are cells of it) */
+    auto need_window = [&]() -> bool { return i - 1 <= R0 || i > R0 + kWinRows || j - 1 < cLo || j > cLo + kWinCols - 1; };
+    auto rfl = [](const int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
     if (algo == DPX_K_LSW) {
         int h = 0;
-        if (i > 0 && j > 0) { load_window(i, j); h = H(i, j); }
+        if (i > 0 && j > 0) { load_window(i, j); h = rfl(win[(i - R0 - 1) * kWinCols + (j - cLo)]); }
         while (h > 0) {
             if (need_window()) load_window(i, j);
-            const int up = H(i - 1, j), left = H(i, j - 1);
-            if (up + g == h) { EMITW('_', ' ', qc_of(i)); i--; h = up; }
-            else if (left + g == h) { EMITW(rc_of(j), ' ', '_'); j--; h = left; }
-            else {
-                const int dg = H(i - 1, j - 1), qc = qc_of(i), rc = rc_of(j);
-                EMITW(rc, qc == rc ? '*' : '|', qc);
-                i--; j--; h = dg;
-            }
+            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
+            const int vu = c[-kWinCols], vl = c[-1], vd = c[-kWinCols - 1], vq = wq[i - R0 - 1], vr = wr[j - cLo]; /* one LDS round trip */
+            const int up = rfl(vu), left = rfl(vl), dg = rfl(vd), qc = rfl(vq), rc = rfl(vr);
+            if (up + g == h) { EMITW('_', ' ', qc); i--; h = up; }
+            else if (left + g == h) { EMITW(rc, ' ', '_'); j--; h = left; }
+            else { EMITW(rc, qc == rc ? '*' : '|', qc); i--; j--; h = dg; }
         }
-    } else {
+    } else if (algo == DPX_K_LNW) {
         while (i != 0 || j != 0) {
-            if (need_window()) load_window(max(i, 1), max(j, 1));
-            if (i == 0) { EMITW(rc_of(j), ' ', '_'); j--; continue; }  /* row-0 border: QUERY_INSERTION */
-            if (j == 0) { EMITW('_', ' ', qc_of(i)); i--; continue; }  /* column-0 border: QUERY_DELETION */
-            const int qc = qc_of(i), rc = rc_of(j);
+            if (need_window()) load_window(max(i, 1), max(j, 1)); /* (a window anchored on row 1 / column 1 also serves row 0 / column 0) */
+            if (i == 0) { const int rc = rfl((int)wr[j - cLo]); EMITW(rc, ' ', '_'); j--; continue; }     /* row-0 border: QUERY_INSERTION */
+            if (j == 0) { const int qc = rfl((int)wq[i - R0 - 1]); EMITW('_', ' ', qc); i--; continue; }  /* column-0 border: QUERY_DELETION */
+            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
+            const int vu = c[-kWinCols], vl = c[-1], vd = c[-kWinCols - 1], vq = wq[i - R0 - 1], vr = wr[j - cLo];
+            const int up = rfl(vu), left = rfl(vl), dg = rfl(vd), qc = rfl(vq), rc = rfl(vr);
             const bool eq = qc == rc;
-            const int mm = H(i - 1, j - 1) + (eq ? match : mismatch);
-            const int del = H(i - 1, j) + g, ins = H(i, j - 1) + g;
+            const int mm = dg + (eq ? match : mismatch);
+            const int del = up + g, ins = left + g;
             const int vmax = max(del, mm);
             if (ins >= vmax) { EMITW(rc, ' ', '_'); j--; }
             else if (del >= mm) { EMITW('_', ' ', qc); i--; }
             else { EMITW(rc, eq ? '*' : '|', qc); i--; j--; }
+        }
+    } else if constexpr (PLANES == 3) { /* ANW: the three-state walk of tb_walk_lane (c++/backtrack.cpp:214-356) */
+        int cur = 0; /* 0 SCORING, 1 INSERTION, 2 DELETION */
+        while (i != 0 && j != 0) {
+            if (need_window()) load_window(i, j);
+            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
+            if (cur == 0) {
+                const int vd = c[-kWinCols - 1], vI = c[kWinPlane], vD = c[2 * kWinPlane], vq = wq[i - R0 - 1], vr = wr[j - cLo];
+                const int dg = rfl(vd), I = rfl(vI), D = rfl(vD), qc = rfl(vq), rc = rfl(vr);
+                const bool eq = qc == rc;
+                const int mm = dg + (eq ? match : mismatch);
+                const int vmax = max(D, mm);
+                if (I >= vmax) cur = 1;
+                else if (D >= mm) cur = 2;
+                else { EMITW(rc, eq ? '*' : '|', qc); i--; j--; }
+            } else if (cur == 1) {
+                const int vh = c[-1], vi = c[kWinPlane - 1], vr = wr[j - cLo];
+                const int hl = rfl(vh), il = rfl(vi), rc = rfl(vr);
+                if (j == 1 || hl + g + ext >= il + ext) cur = 0;
+                EMITW(rc, ' ', '_'); j--;
+            } else {
+                const int vh = c[-kWinCols], vdd = c[2 * kWinPlane - kWinCols], vq = wq[i - R0 - 1];
+                const int hu = rfl(vh), du = rfl(vdd), qc = rfl(vq);
+                if (i == 1 || hu + g + ext >= du + ext) cur = 0;
+                EMITW('_', ' ', qc); i--;
+            }
+        }
+        while (i > 0 || j > 0) { /* along a border to the corner */
+            if (need_window()) load_window(max(i, 1), max(j, 1));
+            if (i > 0) { const int qc = rfl((int)wq[i - R0 - 1]); EMITW('_', ' ', qc); i--; }
+            else { const int rc = rfl((int)wr[j - cLo]); EMITW(rc, ' ', '_'); j--; }
         }
     }
 #undef EMITW
@@ -3401,9 +3479,12 @@ hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, 
                                 const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream) {
     if (numPairs <= 0) return hipSuccess;
     const bool cachedWalk = walk == 1;
-    if (walk == 2) { /* one wave per pair with an LDS window (k_traceback_wave) */
-        hipLaunchKernelGGL(k_traceback_wave, dim3((unsigned)numPairs), dim3(64), 0, stream, a, numPairs, algo, R, planes, a.endRow, a.endCol, tbOff, tb,
-                           tbLen);
+    if (walk == 2 && algo != DPX_K_BSW) { /* one wave per pair with an LDS window (k_traceback_wave) */
+        const size_t lds = dpx_traceback_wave_lds(algo == DPX_K_ANW ? 3 : 1);
+        if (algo == DPX_K_ANW)
+            hipLaunchKernelGGL(k_traceback_wave<3>, dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, algo, R, a.endRow, a.endCol, tbOff, tb, tbLen);
+        else
+            hipLaunchKernelGGL(k_traceback_wave<1>, dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, algo, R, a.endRow, a.endCol, tbOff, tb, tbLen);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,
