@@ -20,7 +20,7 @@ MAT_H, MAT_I, MAT_D = 0, 1, 2
 ABI_VERSION_NEEDED = 3  # include/dpx_align.h DPX_ABI_VERSION: round-3 entry points (dpx_pool_reserve, dpx_batch_last_output_usec) + the pool record in dpx_batch_describe
 
 ABI_SYMBOLS = (
-    "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_pool_reserve", "dpx_strerror", "dpx_last_error",
+    "dpx_init", "dpx_device_count", "dpx_device_info", "dpx_shutdown", "dpx_pool_reserve", "dpx_text_reserve", "dpx_strerror", "dpx_last_error",
     "dpx_abi_version", "dpx_batch_create", "dpx_batch_create_on", "dpx_pack2", "dpx_batch_create_packed2", "dpx_batch_fill", "dpx_batch_fill_timed", "dpx_batch_last_fill_usec", "dpx_batch_last_output_usec", "dpx_batch_sync",
     "dpx_batch_device_results", "dpx_batch_results", "dpx_batch_matrix", "dpx_batch_traceback",
     "dpx_batch_output_begin", "dpx_batch_output_end", "dpx_batch_output_take", "dpx_text_free",
@@ -69,6 +69,7 @@ def load() -> C.CDLL:
     lib.dpx_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.dpx_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     lib.dpx_pool_reserve.argtypes = [C.c_size_t, C.c_int]
+    lib.dpx_text_reserve.argtypes = [C.c_size_t, C.c_int]
     lib.dpx_strerror.argtypes = [C.c_int]
     lib.dpx_strerror.restype = C.c_char_p
     lib.dpx_last_error.restype = C.c_char_p

@@ -218,7 +218,9 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual, bool *fresh) 
             const Entry &e = parked_[i];
             /* (a parked matrix pool of up to 13 GiB serves any smaller batch: a driver that cuts a file into batches of one pool
              * budget ends with a short batch, and a pool reserved ahead of time -- dpx_pool_reserve -- is sized by the budget) */
-            const size_t roof = kind_ == DevicePool ? std::max(need + need / 2 + (1u << 20), (size_t)13 << 30) : need + need / 2 + (1u << 20);
+            /* (a parked pinned buffer of up to 32 MiB -- dpx_text_reserve -- serves any smaller text) */
+            const size_t roof = kind_ == DevicePool ? std::max(need + need / 2 + (1u << 20), (size_t)13 << 30)
+                                : (kind_ == PinnedHost && need >= ((size_t)2 << 20)) ? std::max(need + need / 2 + (1u << 20), (size_t)32 << 20) : need + need / 2 + (1u << 20);
             if (e.device != t_device || e.bytes < need || e.bytes > roof) continue;
             if (best == parked_.size() || e.bytes < parked_[best].bytes) best = i;
         }
@@ -529,6 +531,22 @@ int dpx_pool_reserve(size_t bytes, int count) {
         if (e != hipSuccess) { for (int j = 0; j < k; j++) g_matCache.park(p[j], got[j]); return hip_fail(e, "dpx_pool_reserve"); }
     }
     for (int k = 0; k < count; k++) g_matCache.park(p[k], got[k]);
+    return DPX_OK;
+}
+
+/* The same for the pinned host buffers that the result text of a batch is copied into (dpx_batch_output_end / _take): pinning
+ * 8 MB costs 1-2 ms, and a pipelined driver holds up to three of them (one being printed, two batches in flight). */
+int dpx_text_reserve(size_t bytes, int count) {
+    if (count < 1 || count > 4 || bytes == 0 || bytes > ((size_t)1 << 30)) return DPX_ERR_INVALID;
+    int rc = bind_device();
+    if (rc != DPX_OK) return rc;
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t got[4] = {0, 0, 0, 0};
+    for (int k = 0; k < count; k++) {
+        hipError_t e = g_tbHostCache.take(&p[k], bytes, &got[k]);
+        if (e != hipSuccess) { for (int j = 0; j < k; j++) g_tbHostCache.park(p[j], got[j]); return hip_fail(e, "dpx_text_reserve"); }
+    }
+    for (int k = 0; k < count; k++) g_tbHostCache.park(p[k], got[k]);
     return DPX_OK;
 }
 

@@ -2908,12 +2908,8 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
     const int Rr = pr.rows ? (int)pr.rows : R;
-    const bool eligible = (PLANES == 3 ? algo == DPX_K_ANW : (algo == DPX_K_LSW || algo == DPX_K_LNW)) && (Rr == 2 || Rr == 4 || Rr == 8 || Rr == 16) &&
-                          (pr.lanes == 64 || pr.lanes == 16 || pr.lanes == 32) && m > 0 && n > 0;
-    if (!eligible) { /* banded matrices, empty sequences: the one-lane walk (wave-uniform branch) */
-        if (lane == 0) tb_walk_lane(a, p, algo, R, PLANES, 0, endRow, endCol, tbOff, tb, tbLen);
-        return;
-    }
+    /* (the host launches this kernel for LSW / LNW with one plane and ANW with three, never for banded matrices; rows per lane are
+     * 2, 4, 8 or 16 in every layout; empty sequences walk along a border or not at all) */
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
     const int16_t *base = a.mat + pr.matOff;

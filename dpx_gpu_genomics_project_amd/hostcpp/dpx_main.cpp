@@ -102,7 +102,8 @@ int main(int argc, char *argv[]) {
     // as many pairs -- and fills the chip as well -- as a linear-gap batch of the same shapes)
     const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
     std::thread reserve;
-    if (batchSize == 0) reserve = std::thread([poolBudget]() { (void)dpx_pool_reserve(poolBudget, 2); });
+    // (and three pinned text buffers: one being printed, two batches in flight)
+    if (batchSize == 0) reserve = std::thread([poolBudget, print]() { (void)dpx_pool_reserve(poolBudget, 2); if (print) (void)dpx_text_reserve((size_t)16 << 20, 3); });
 
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;

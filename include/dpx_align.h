@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* 1: round 1.  2: + dpx_batch_create_on, dpx_batch_fill_timed, dpx_batch_last_fill_usec, dpx_batch_output_begin/_end/_take,
- * dpx_text_free, DPX_TUNE_PLACEMENT (round 2).  3: + dpx_pool_reserve, dpx_batch_last_output_usec, dpx_pack2, dpx_batch_create_packed2; dpx_batch_describe reports the
+ * dpx_text_free, DPX_TUNE_PLACEMENT (round 2).  3: + dpx_pool_reserve, dpx_text_reserve, dpx_batch_last_output_usec, dpx_pack2, dpx_batch_create_packed2; dpx_batch_describe reports the
  * matrix pool (round 3).  Additions only: a caller built against an older version keeps working; dpx_abi_version() >= the version
  * a caller needs is the check. */
 #define DPX_ABI_VERSION 3
@@ -98,6 +98,9 @@ int dpx_shutdown(void);
  * whose matrices fit takes a parked pool instead of allocating).  Meant for a helper thread while the caller parses its input:
  * the reference sizes its device buffers once, before the batch loop (cuda/LNW/LinearNeedlemanWunschV14.cu:144-213). */
 int dpx_pool_reserve(size_t bytes, int count);
+/* The same for `count` (1..4) pinned host buffers of `bytes` (<= 1 GiB) each, which the result text of the batches to come is copied
+ * into (dpx_batch_output_end / _take; a parked buffer of up to 32 MiB serves any text of 2 MiB or more that fits). */
+int dpx_text_reserve(size_t bytes, int count);
 const char *dpx_strerror(int status);
 const char *dpx_last_error(void); /* thread-local text of the last HIP failure */
 int dpx_abi_version(void);
