@@ -8,7 +8,7 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-pack2] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-pack2] [-producer 0|1] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
@@ -23,6 +23,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,6 +59,7 @@ int main(int argc, char *argv[]) {
     size_t batchSize = 0;     // 0: from the pool budget (the reference's BATCH_SIZE, V19.cu:9, assumes short reads)
     double poolGb = 4.0;
     bool print = true, pack2 = false;
+    int producerFlag = -1; // -1: by batch size
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -74,6 +78,7 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-device")) device = atoi(next("-device"));
         else if (!strcmp(argv[i], "-noprint")) print = false;
         else if (!strcmp(argv[i], "-pack2")) pack2 = true;
+        else if (!strcmp(argv[i], "-producer")) producerFlag = atoi(next("-producer"));
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
@@ -141,9 +146,9 @@ int main(int argc, char *argv[]) {
     const dpx_params prm{algo, match, mismatch, gapOpen, gapExtend, band};
     static_assert(sizeof(seqPair) == sizeof(dpx_seq_pair), "seqPair must stay layout-compatible with the C ABI");
 
-    // pipeline: [create + fill + output_begin] of batch k+1 is issued before batch k is waited for; the printer thread
-    // writes batch k-1 meanwhile from the text buffer it took over, so batch k-1 itself is destroyed (its matrix pool
-    // parked for batch k+1) as soon as its text is on the host.
+    // pipeline of three host threads: the producer issues [create + fill + output_begin] of batch k+1 while this thread waits
+    // for batch k and takes its text; the printer thread writes batch k-1 meanwhile from the text buffer it took over, so batch
+    // k-1 itself is destroyed (its matrix pool parked for batch k+1) as soon as its text is on the host.
     std::thread printer;
     char *printingText = nullptr;
     InFlight filling; // issued to the device, not yet waited for
@@ -174,29 +179,81 @@ int main(int argc, char *argv[]) {
     size_t shardCells = 0;
     for (size_t i = shardLo; i < shardHi; i++) shardCells += (size_t)sequenceIdxs[i].referenceSize * (size_t)sequenceIdxs[i].querySize;
     fflush(stdout); // the printer thread writes with fwrite from here on
-    for (size_t first = shardLo; first < shardHi; first += batchSize) {
+    // One batch: create, fill, start the output.  Two batches alive need two matrix pools.  Allocating tens of GB costs hundreds of
+    // ms (more than the overlap of one batch's traceback with the next batch's fill can ever win back), so batches with pools of
+    // 16 GiB or more (an explicit -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
+    size_t maxAlive = 2;
+    uint64_t create_time = 0; // written by the thread that produces, read after it is done
+    auto produce = [&](size_t first) -> InFlight {
         InFlight next;
         next.first = first;
         next.count = std::min(batchSize, shardHi - first);
-        uint64_t t0 = get_time();
-        rc = pack2 ? dpx_batch_create_packed2(-1, &prm, packed.data(), fileInfo.numBytes, alphabet, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs),
-                                              first, next.count, DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b)
-                   : dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
-                                      DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
-        if (rc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", rc);
-        memalloc_time += get_time() - t0;
-        if ((rc = dpx_batch_fill(next.b, nullptr)) != DPX_OK) die("KERNEL LAUNCH FAILED", rc);
+        const uint64_t t0 = get_time();
+        int prc = pack2 ? dpx_batch_create_packed2(-1, &prm, packed.data(), fileInfo.numBytes, alphabet, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs),
+                                                   first, next.count, DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b)
+                        : dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
+                                           DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
+        if (prc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", prc);
+        create_time += get_time() - t0;
+        if ((prc = dpx_batch_fill(next.b, nullptr)) != DPX_OK) die("KERNEL LAUNCH FAILED", prc);
         // global pair numbers: shardFirst + index inside the shard
-        if (print && (rc = dpx_batch_output_begin(next.b, shardFirst + first)) != DPX_OK) die("TRACEBACK LAUNCH FAILED", rc);
-        if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
-        filling = next;
-        // Two batches in flight need two matrix pools.  Allocating tens of GB costs hundreds of ms (more than the overlap of one
-        // batch's traceback with the next batch's fill can ever win back), so batches with pools of 16 GiB or more (an explicit
-        // -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
-        uint64_t matrixBytes = 0;
-        dpx_batch_info(filling.b, nullptr, nullptr, &matrixBytes, nullptr);
-        if (matrixBytes >= (16ull << 30)) finish(filling);
+        if (print && (prc = dpx_batch_output_begin(next.b, shardFirst + first)) != DPX_OK) die("TRACEBACK LAUNCH FAILED", prc);
+        return next;
+    };
+    auto pool_is_huge = [](const InFlight &f) { uint64_t mb = 0; dpx_batch_info(f.b, nullptr, nullptr, &mb, nullptr); return mb >= (16ull << 30); };
+    // Batches of many short pairs are bound by the HOST (dpx_batch_create: 1.1-1.4 ms per 20000 pairs for validation, two counting
+    // sorts, the wave packing and the H2D copies, against 0.15 + 0.3 ms of kernels): a producer thread issues batch k+1 while this
+    // thread waits for batch k, takes its text and hands it to the printer (100k short reads: 12 -> 7.5 ms).  Batches of few long
+    // pairs are bound by the device, and there one issuing thread is as fast or faster (10000 x 1024^2: 8.1-8.9 vs 8.4-9.3 ms).
+    // -producer 0|1 overrides.
+    const bool threaded = producerFlag >= 0 ? producerFlag != 0 : batchSize >= 8192;
+    if (threaded) {
+        std::mutex qm;
+        std::condition_variable qcv;
+        std::deque<InFlight> ready;
+        size_t alive = 0;
+        bool produced = false;
+        std::thread producer([&]() {
+            for (size_t first = shardLo; first < shardHi; first += batchSize) {
+                {
+                    std::unique_lock<std::mutex> lk(qm);
+                    qcv.wait(lk, [&]() { return alive < maxAlive; });
+                }
+                const InFlight next = produce(first);
+                const bool huge = pool_is_huge(next);
+                std::lock_guard<std::mutex> lk(qm);
+                if (huge) maxAlive = 1;
+                ready.push_back(next);
+                alive++;
+                qcv.notify_all();
+            }
+            std::lock_guard<std::mutex> lk(qm);
+            produced = true;
+            qcv.notify_all();
+        });
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(qm);
+                qcv.wait(lk, [&]() { return !ready.empty() || produced; });
+                if (ready.empty()) break;
+                filling = ready.front();
+                ready.pop_front();
+            }
+            finish(filling); // (destroys the batch: its pool is parked for the producer's next one)
+            std::lock_guard<std::mutex> lk(qm);
+            alive--;
+            qcv.notify_all();
+        }
+        producer.join();
+    } else {
+        for (size_t first = shardLo; first < shardHi; first += batchSize) {
+            const InFlight next = produce(first);
+            if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
+            filling = next;
+            if (pool_is_huge(filling)) finish(filling);
+        }
     }
+    memalloc_time += create_time;
     if (filling.b) finish(filling);
     retire_printed();
     fflush(stdout);

@@ -107,6 +107,9 @@ def test_batches_from_the_pool_budget_print_the_same_text(tmp_path):
         auto = body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo, "-pool-gb", "0.0625"]))
         dflt = body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo]))
         assert one == auto == dflt
+        # the producer thread (default for batches of >= 8192 pairs) issues batch k+1 while batch k is waited for: same text, batch by batch
+        for prod in ("0", "1"):
+            assert body(run([os.path.join(HOST, "dpx_main"), "-pairs", path] + W[algo] + ["-algo", algo, "-batch", "7", "-producer", prod])) == one
         if algo == "LSW":
             for p in (0, 41, 42, 99):
                 assert f"\n{p} | {O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, want_dir=False).score}\n" in "\n" + one
