@@ -77,3 +77,26 @@ def test_reserved_pools_serve_the_batches_that_follow(gpu):
         o = O.lsw(sb.ref(7), sb.qry(7), *W, want_dir=False)
         assert b1.results()[0][7] == o.score
     lib.dpx_shutdown(); gpu.init(0)
+
+
+def test_reserved_text_buffers_serve_the_output_of_the_batches_that_follow(gpu):
+    """dpx_text_reserve (round 3): pinned host buffers for the result text, built ahead of time like the pools.  A reserved buffer of up to
+    32 MiB serves any text of 2 MiB or more; smaller texts (and the per-pair offset tables) never take one; the text is the same."""
+    lib = gpu.load()
+    lib.dpx_shutdown(); gpu.init(0)
+    assert lib.dpx_text_reserve(16 << 20, 3) == 0
+    assert lib.dpx_text_reserve(0, 1) == -1 and lib.dpx_text_reserve(1 << 20, 5) == -1 and lib.dpx_text_reserve(2 << 30, 1) == -1   # DPX_ERR_INVALID
+    big, small = make_batch(900, 700, 900, seed=24), make_batch(20, 60, 70, seed=25)                 # ~4.3 MB and ~8 KB of text
+    texts = []
+    for _ in range(2):
+        for sb in (big, small):
+            with gpu.Batch(gpu.ALGO_LNW, sb.sequences, sb.pairs, *W) as b:
+                b.fill()
+                b.output_begin(0)
+                text, offs = b.output_end()
+                assert offs[-1] == len(text) and text.count(b"\n") == 4 * sb.num_pairs
+                texts.append(text)
+        lib.dpx_shutdown(); gpu.init(0)                          # second round: nothing reserved
+    assert texts[0] == texts[2] and texts[1] == texts[3]
+    o = O.lnw(big.ref(3), big.qry(3), *W)
+    assert f"\n3 | {o.score}\n".encode() in texts[0]
