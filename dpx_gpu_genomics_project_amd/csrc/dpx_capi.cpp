@@ -1082,7 +1082,8 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     {
         bool anyEmpty = false;
         for (size_t i = 0; i < numPairs && !anyEmpty; i++) anyEmpty = b->pairs[i].m <= 0 || b->pairs[i].n <= 0;
-        const int sR = b->maxM > 256 ? 4 : 2; /* (queries over 4096 rows would need more than 16 stripes: not split) */
+        int sR = b->maxM > 256 ? 4 : 2; /* (queries over 4096 rows would need more than 16 stripes: not split) */
+        if (const char *env = getenv("DPX_SPLIT_R")) { const int v = atoi(env); if (v == 2 || v == 4) sR = v; } /* experiments: twice the stripes at 2 rows per lane */
         const int sW = dpx_tiled_stripes(b->maxM, sR);
         const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
         const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;
