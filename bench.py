@@ -73,8 +73,9 @@ def pool_record(desc: dict) -> dict:
     nbytes = int(desc.get("pool_bytes", 0))
     kept = int(desc.get("pool_kept", 0))
     fills = [float(x) for x in str(desc.get("pool_fill_ms", "")).split(",") if x and x != "unshopped"]
+    kinds = [x for x in str(desc.get("pool_kinds", "")).split(",") if x]
     return {"mode": desc["pool"], "bytes": nbytes, "chunk_mb": int(desc.get("pool_chunk_mb", 0)), "candidates_memset_ms": ms,
-            "candidates_fill_ms": fills, "kept": kept,
+            "candidates_fill_ms": fills, "candidates_kind": kinds, "kept": kept,
             "memset_tbps": round(nbytes / (ms[kept] * 1e-3) / 1e12, 3) if len(ms) > kept and ms[kept] > 0 else None}
 
 

@@ -83,6 +83,9 @@ std::mutex g_vmmMu;
 std::map<void *, VmmRange> g_vmmRanges;
 struct PoolStats { const char *mode = "malloc"; size_t chunkBytes = 0; }; /* what the last pool_alloc of this thread did */
 thread_local PoolStats t_poolStats;
+/* how the next pool_alloc of this thread builds its pool (shop_pool_by_fill compares constructions): 0 = the default (256-MiB chunks,
+ * or what DPX_POOL / DPX_POOL_CHUNK_MB say), > 0 = chunks of this many bytes, -1 = one hipMalloc */
+thread_local long long t_poolBuild = 0;
 
 /* Tearing a range down: ROCm 7.2 crashed inside hipMemAddressFree in about half the runs of the pool tests (shopping for a pool
  * builds and drops candidates next to a live one; native backtrace + call trace: profiles/r03/vmm_address_free_crash.txt), and with
@@ -117,9 +120,9 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     const bool useMalloc = [] { const char *e = getenv("DPX_POOL"); return e && !strcmp(e, "malloc"); }();
     const size_t chunkEnv = [] { const char *e = getenv("DPX_POOL_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
     t_poolStats = PoolStats();
-    if (useMalloc || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
+    if ((t_poolBuild == 0 ? useMalloc : t_poolBuild < 0) || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
     const size_t gran = (size_t)2 << 20;
-    const size_t chunk = align_up(chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
+    const size_t chunk = align_up(t_poolBuild > 0 ? (size_t)t_poolBuild : chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
     VmmRange r;
     r.bytes = align_up(bytes, gran);
     r.device = t_device;
@@ -352,6 +355,7 @@ struct PoolRecord {
     size_t bytes = 0, chunkBytes = 0;
     std::vector<float> candidatesMs; /* hipMemset time of every candidate allocation (empty: never timed) */
     std::vector<float> fillMs;       /* time of one fill of the batch on every candidate (empty: never shopped) */
+    std::vector<std::string> kinds;  /* how every candidate was built: "vmm256", "vmm1024", "malloc" ... (empty: never shopped) */
     int kept = 0;
 };
 static std::mutex g_poolRecMu;
@@ -737,23 +741,36 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
     float bestMs = time_fill();
     rec.fillMs.assign(1, bestMs);
     rec.kept = 0;
+    auto kind_of = [](const char *mode, size_t chunkBytes) { return !strcmp(mode, "vmm") ? "vmm" + std::to_string(chunkBytes >> 20) : std::string(mode); };
+    rec.kinds.assign(1, kind_of(rec.mode.c_str(), rec.chunkBytes));
+    /* The candidates differ in CONSTRUCTION (round 3, tools/group_sweep.sh on a slow box of the pool: the headline fill takes 3.82 ms on
+     * 256-MiB chunks, 3.58 on one hipMalloc, 3.37 on 1-GiB chunks -- on the fast boxes 256-MiB chunks win, 3.2 against 3.3-3.6):
+     * 1-GiB chunks, one hipMalloc, then the first construction once more.  With DPX_POOL / DPX_POOL_CHUNK_MB set every candidate is
+     * built the way they say (up to three more of them, as before). */
+    const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB");
+    const long long builds[3] = {forced ? 0 : (long long)1 << 30, forced ? 0 : -1, 0};
     float lo = bestMs, hi = bestMs;
     for (int k = 1; k < 4 && bestMs > 0.f; k++) {
-        if (k >= 2 && hi > lo * 1.03f) break; /* both modes seen */
+        if (forced && k >= 2 && hi > lo * 1.03f) break; /* both modes of one construction seen */
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; }
         void *cand = nullptr;
-        if (pool_alloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        t_poolBuild = builds[k - 1];
+        const hipError_t ae = pool_alloc(&cand, bytes);
+        t_poolBuild = 0;
+        if (ae != hipSuccess) { (void)hipGetLastError(); break; }
+        const PoolStats built = t_poolStats;
         set_pool(cand);
         const float ms = time_fill();
         rec.fillMs.push_back(ms);
+        rec.kinds.push_back(kind_of(built.mode, built.chunkBytes));
         rec.candidatesMs.push_back(time_memset(cand, bytes, b->stream));
         if (ms > 0.f) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
-        if (ms > 0.f && ms < bestMs) { pool_free(best); best = cand; bestMs = ms; rec.kept = k; }
+        if (ms > 0.f && ms < bestMs) { pool_free(best); best = cand; bestMs = ms; rec.kept = k; rec.mode = built.mode; rec.chunkBytes = built.chunkBytes; }
         else pool_free(cand);
     }
     set_pool(best);
-    if (trace.on) for (size_t k = 0; k < rec.fillMs.size(); k++) fprintf(stderr, "[dpx] pool candidate %zu: fill %.3f ms%s\n", k, rec.fillMs[k], (int)k == rec.kept ? "  <- kept" : "");
+    if (trace.on) for (size_t k = 0; k < rec.fillMs.size(); k++) fprintf(stderr, "[dpx] pool candidate %zu (%s): fill %.3f ms%s\n", k, rec.kinds[k].c_str(), rec.fillMs[k], (int)k == rec.kept ? "  <- kept" : "");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
@@ -1831,6 +1848,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
         for (size_t k = 0; k < r.fillMs.size() && (size_t)len < cap; k++)
             len += snprintf(buf + len, cap - (size_t)len, "%s%.3f", k ? "," : "", r.fillMs[k]);
         if (r.fillMs.empty() && (size_t)len < cap) len += snprintf(buf + len, cap - (size_t)len, "unshopped");
+        if (!r.kinds.empty() && (size_t)len < cap) {
+            len += snprintf(buf + len, cap - (size_t)len, " pool_kinds=");
+            for (size_t k = 0; k < r.kinds.size() && (size_t)len < cap; k++) len += snprintf(buf + len, cap - (size_t)len, "%s%s", k ? "," : "", r.kinds[k].c_str());
+        }
     }
     return DPX_OK;
 }
