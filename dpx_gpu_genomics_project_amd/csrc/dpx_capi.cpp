@@ -630,6 +630,7 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
     constexpr size_t kWindow = 256; /* open waves: pairs arrive sorted by reference length, so a window keeps a wave's pairs alike */
     std::vector<Bin> bins;          /* in opening order = emission order */
     std::vector<int32_t> byFree[65]; /* open bins by free lanes (entries go stale when a bin moves on: checked on use) */
+    uint64_t nonEmpty = 0;           /* bit f-1: byFree[f] holds entries (the search skips the empty buckets with one ctz) */
     size_t oldestOpen = 0, numOpen = 0;
     bins.reserve(idx.size() / 3 + 8);
     for (int32_t i : idx) {
@@ -637,7 +638,8 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
         const int L = (pd.m + R - 1) / R;
         const size_t need = align_up((size_t)pd.n + 31, 16);
         int best = -1;
-        for (int f = L; f <= 64 && best < 0; f++) { /* tightest fit first */
+        for (uint64_t cand = L <= 64 ? nonEmpty & (~0ull << (L - 1)) : 0; cand && best < 0; cand &= cand - 1) { /* tightest fit first */
+            const int f = __builtin_ctzll(cand) + 1;
             std::vector<int32_t> &lst = byFree[f];
             while (!lst.empty()) {
                 const int32_t k = lst.back();
@@ -648,6 +650,7 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
                 lst.pop_back();
                 break;
             }
+            if (lst.empty()) nonEmpty &= ~(1ull << (f - 1));
         }
         if (best < 0) {
             if (numOpen >= kWindow) { /* retire the oldest open wave */
@@ -668,7 +671,7 @@ static size_t pack_waves(const std::vector<dpx_pair_dev> &pairs, std::vector<int
         bn.lanes += L;
         bn.slots++;
         bn.ref += need;
-        if (bn.lanes < 64 && bn.slots < maxSlots) byFree[64 - bn.lanes].push_back(best);
+        if (bn.lanes < 64 && bn.slots < maxSlots) { byFree[64 - bn.lanes].push_back(best); nonEmpty |= 1ull << (64 - bn.lanes - 1); }
         else { bn.closed = true; numOpen--; }
     }
     std::vector<int32_t> order;
@@ -906,6 +909,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         if (pd.n != b->pairs[0].n || pd.m != b->pairs[0].m) ragged = true;
     }
 
+    trace.mark("create: validation");
     /* rows per lane: smallest tile that keeps short queries in one stripe, 8 (or DPX_R) otherwise */
     /* linear gaps: 16 rows per lane once a query is longer than 512 (one stripe up to 1024 rows, two 1-KiB sub-tiles per
      * step: measured 4 % faster than 8 rows x 2 rolling stripes); the affine kernel carries three chains and stays at 8 */
@@ -1030,12 +1034,14 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
             pass(couples, tmp, b->maxM, [&](int32_t c) { return b->pairs[c].m; });
             pass(tmp, couples, b->maxN, [&](int32_t c) { return b->pairs[c].n; });
         }
+        trace.mark("create: lanes sort");
         lanesPairs = couples.size();
         b->lanePacked = !couples.empty();
         if (b->lanePacked) {
             /* (reference area: 1 KiB keeps four workgroups of the 8-rows-per-lane kernels on a CU, up to 8 pairs per wave as in round 2; the
              * packed kernel's pairs take half the lanes, so its waves hold up to 12 pairs in 2 KiB: 2 x (18 + 2) KiB x 4 waves = 160 KiB) */
             lanesRefArea = pack_waves(b->pairs, couples, kLanesR, b->maxN, lanesPk ? 2048 : 1024, lanesPk ? DPX_WAVE_SLOTS : 8, waves); /* `couples` comes back in slot order */
+            trace.mark("create: pack_waves");
             size_t lanesUsed = 0;
             for (const dpx_wave_desc &wd : waves) for (int k = 0; k < DPX_WAVE_SLOTS; k++) lanesUsed += wd.num[k];
             if (!lanesForced && lanesUsed * 100 < waves.size() * 64 * 85) b->lanePacked = false; /* under 85 % of the lanes own rows: not worth it */
