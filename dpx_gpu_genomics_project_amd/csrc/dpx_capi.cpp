@@ -719,10 +719,10 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s);
 /* DPX_TUNE_PLACEMENT (callers that fill a resident batch many times: bench.py, iterative drivers).  The same fill runs up to
  * 27 % apart on two pools of the same construction (ANW 1000 x 1024^2: 1.05 vs 1.20 ms, alternating from one allocation to the
  * next while hipMemset sees no difference; LSW 10k x 1024^2: +-2 %; tools/mode_watch.py, profiles/r03/): the mode belongs to the
- * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: up to
- * four candidate pools, one warm-up + three timed fills each, the fastest is kept (and parked for later batches), the loser of
- * every comparison is freed at once (never more than two pools alive).  Stops early once two candidates differ by more than 3 %
- * (both modes seen).  Every candidate's times go into the pool record (dpx_batch_describe -> bench.py roofline.pool). */
+ * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: five
+ * candidate pools of different constructions (see below), one warm-up + three timed fills each, the fastest is kept (and parked for
+ * later batches), the loser of every comparison is freed at once (never more than two pools alive).  Every candidate's
+ * construction and times go into the pool record (dpx_batch_describe -> bench.py roofline.pool). */
 static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -748,12 +748,13 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
     rec.kinds.assign(1, kind_of(rec.mode.c_str(), rec.chunkBytes));
     /* The candidates differ in CONSTRUCTION (round 3, tools/group_sweep.sh on a slow box of the pool: the headline fill takes 3.82 ms on
      * 256-MiB chunks, 3.58 on one hipMalloc, 3.37 on 1-GiB chunks -- on the fast boxes 256-MiB chunks win, 3.2 against 3.3-3.6):
-     * 1-GiB chunks, one hipMalloc, then the first construction once more.  With DPX_POOL / DPX_POOL_CHUNK_MB set every candidate is
-     * built the way they say (up to three more of them, as before). */
+     * 1-GiB, 2-GiB and 512-MiB chunks, then the first construction once more (one hipMalloc, like one chunk for the whole pool, never
+     * won: 3.58-3.7 ms everywhere).  With DPX_POOL / DPX_POOL_CHUNK_MB set every candidate is built the way they say (up to three
+     * more of them, as before). */
     const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB");
-    const long long builds[3] = {forced ? 0 : (long long)1 << 30, forced ? 0 : -1, 0};
+    const long long builds[4] = {forced ? 0 : (long long)1 << 30, forced ? 0 : (long long)2 << 30, forced ? 0 : (long long)512 << 20, 0};
     float lo = bestMs, hi = bestMs;
-    for (int k = 1; k < 4 && bestMs > 0.f; k++) {
+    for (int k = 1; k < (forced ? 4 : 5) && bestMs > 0.f; k++) {
         if (forced && k >= 2 && hi > lo * 1.03f) break; /* both modes of one construction seen */
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; }
