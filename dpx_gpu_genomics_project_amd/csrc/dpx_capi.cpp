@@ -535,6 +535,17 @@ int dpx_pool_reserve(size_t bytes, int count) {
         if (e != hipSuccess) { for (int j = 0; j < k; j++) g_matCache.park(p[j], got[j]); return hip_fail(e, "dpx_pool_reserve"); }
     }
     for (int k = 0; k < count; k++) g_matCache.park(p[k], got[k]);
+    /* ... and the streams of the batches that will take the pools: a batch runs on its own stream plus a side stream for the pairs its
+     * main kernel leaves over (an odd pair beside the couples of the packed kernel), and creating a stream costs ~10 ms each time the
+     * cache is empty (DPX_TRACE of the batched driver: "create: stream 9.6 ms" twice for two batches in flight) */
+    {
+        hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};
+        int made = 0;
+        for (int k = 0; k < 2 * count; k++)
+            if (hipStreamCreateWithFlags(&extra[made], hipStreamNonBlocking) == hipSuccess) made++;
+            else (void)hipGetLastError();
+        for (int k = 0; k < made; k++) stream_park(extra[k]);
+    }
     return DPX_OK;
 }
 
@@ -715,6 +726,17 @@ static float time_memset(void *p, size_t bytes, hipStream_t s) {
 }
 
 static hipError_t launch_all(dpx_batch *b, hipStream_t s);
+
+/* Waves per workgroup of the one-wave-per-pair / -couple kernels.  Their waves share nothing, so the workgroup is only the unit in which
+ * the dispatcher hands waves to CUs: with four-wave workgroups 1250 waves are 313 workgroups on 256 CUs -- 57 CUs get eight waves, the
+ * others four, and the launch takes as long as eight (tools/pairs_sweep.py: 2500 pairs of 1024^2 on the packed kernel 2322 GCUPS, 1900
+ * pairs = 238 workgroups 3265).  Small launches therefore use one-wave workgroups (the CUs differ by at most one wave); big ones keep
+ * four (a few per cent faster there: fewer workgroups to dispatch, profiles/r03/ab_nontemporal_stores_and_wg64.txt).  DPX_WPB=1|4 forces one. */
+static uint32_t fill_waves_per_block(size_t waves) {
+    if (const char *env = getenv("DPX_WPB")) { const int v = atoi(env); if (v == 1 || v == 4) return (uint32_t)v; }
+    static const size_t small = [] { const char *e = getenv("DPX_WPB_SMALL"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)4096; }();
+    return waves <= small ? 1u : 4u;
+}
 
 /* DPX_TUNE_PLACEMENT (callers that fill a resident batch many times: bench.py, iterative drivers).  The same fill runs up to
  * 27 % apart on two pools of the same construction (ANW 1000 x 1024^2: 1.05 vs 1.20 ms, alternating from one allocation to the
@@ -1057,8 +1079,14 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
             for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 64; b->pairs[i].rows = 0; }
         }
     }
+    /* small batches need every wave they can get: one pair per wave there.  Measured with one-wave workgroups (round 3,
+     * tools/pairs_sweep.py, profiles/r03/kernel_choice_by_batch_size.txt; GCUPS packed / one wave per pair / split): 1024 x 1024 at 1000
+     * pairs 2014 / 2813 / 2615, 1500: 2971 / 2622 / 2487, 1900: 3052 / 2770 / 2650, 2500: 2749 / 2731 / 2683, 4000: 3226 / 2993 / 2650 --
+     * the 16-rows-per-lane packed kernel wins from ~700 couples on; 512 x 512 (8 rows per lane) at 1500: 2235 / 2060 / 1987, 2000: 2432 /
+     * 2495 / 2211, 3000: 2334 / 2744 / 2446, 4000: 2877 / 2811 / 2478 -- there only from ~2000 couples on */
+    const size_t pkMinPairs = (linearAlgo && b->R == 16) ? 1400 : 4096;
     bool usePacked = !b->lanePacked && b->store && ((linearAlgo && dpx_tiled_stripes(b->maxM, b->R) == 1) || banded) &&
-                     numPairs >= 4096; /* small batches need every wave they can get: one pair per wave there */
+                     numPairs >= pkMinPairs;
     if (b->lanePacked) usePacked = false;
     else
     if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (linearAlgo || banded);
@@ -1116,8 +1144,12 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
          *   1024 x 1024 (4 stripes of 4 rows per lane against ONE 16-rows-per-lane wave): 600 pairs 1864 vs 1768, 1200: 2229 vs 1765,
          *   2500: 2483 vs 2315, 3500: 2592 vs 2393, 4096: 2603 vs 2671 (and the packed kernel takes over);
          *   512 x 512 (2 stripes against one 8-rows-per-lane wave): 500 pairs 1021 vs 1003, 1000: 2084 vs 2003, 1500: 1841 vs 1935.
-         * So: any shape up to ~1100 pairs, shapes of four or more stripes up to the packed kernel's threshold. */
-        bool useSplit = shape && (numPairs <= 1100 || (sW >= 4 && numPairs < 4096));
+         * So: any shape up to ~1100 pairs, shapes of four or more stripes up to the packed kernel's threshold.
+         * Round 3, with one-wave workgroups for the one-wave-per-pair kernels (tools/pairs_sweep.py; split vs one wave per pair): 1024 x 1024
+         * 300 pairs 1373 vs 855, 600: 2111 vs 1699, 1000: 2615 vs 2805, 1500: 2487 vs 2622, 3000: 2636 vs 2779-2962; 512 x 512 600 pairs 1323 vs
+         * 1173, 1000: 1943 vs 1932, 1500: 1987 vs 2060, 3000: 2446 vs 2744 -- queries that fit one stripe of the other kernels (<= 1024
+         * rows) split only up to ~900 pairs (up to 512 rows: ~1100, a tie from there on); longer ones (the other kernels roll over several stripes) as before. */
+        bool useSplit = shape && (b->maxM > 1024 ? (numPairs <= 1100 || (sW >= 4 && numPairs < 4096)) : numPairs <= (b->maxM > 512 ? 900u : 1100u));
         if (const char *env = getenv("DPX_SPLIT")) useSplit = atoi(env) != 0 && shape;
         if (useSplit) {
             b->split = true;
@@ -1387,6 +1419,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     a.pairs = b->dPairs;
     a.order = b->dOrder;
     a.numPairs = (int32_t)numSingles;
+    a.wavesPerBlock = fill_waves_per_block(numSingles);
     a.match = params->match; a.mismatch = params->mismatch;
     a.gapOpen = params->gapOpen; a.gapExtend = params->gapExtend; a.band = params->band;
     a.mat = b->dMat;
@@ -1415,6 +1448,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         a.ldsQryOff = (uint32_t)(edgeBytes + refB);
         a.ldsBufStride = (uint32_t)(refB + qB);
         a.ldsPerWave = (uint32_t)(edgeBytes + 2 * (refB + qB));
+        a.wavesPerBlock = 4; /* (persistent waves: one launch of numStreams waves) */
         b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), kLdsFloor);
         if (b->streamLds > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
@@ -1423,6 +1457,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         k = a;
         k.order = b->dCouples;
         k.numPairs = (int32_t)numCouples;
+        k.wavesPerBlock = fill_waves_per_block(numCouples);
         const size_t q2 = align_up(((size_t)b->maxM + 96) * 2, 16), r2 = align_up(((size_t)b->maxN + 32) * 2, 16);
         k.ldsPerWave = (uint32_t)(q2 + r2);
         k.ldsRefOff = (uint32_t)q2;
@@ -1432,6 +1467,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         k = a;
         k.order = b->dCouples;
         k.numPairs = (int32_t)numCouples;
+        k.wavesPerBlock = fill_waves_per_block(numCouples);
         const size_t pkEdge = align_up((size_t)(b->maxN + 2) * 4, 16);
         const size_t pkRef = align_up(((size_t)b->maxN + 128) * 2, 16);
         k.ldsPerWave = (uint32_t)(pkEdge + pkRef);

@@ -29,6 +29,7 @@ typedef struct dpx_fill_args {
     int16_t *mat;               /* matrix pool (int16, engine layout) or NULL when score-only */
     int32_t *score, *endRow, *endCol;
     uint32_t ldsPerWave;        /* bytes of dynamic LDS per wave */
+    uint32_t wavesPerBlock;     /* independent waves per workgroup of the one-wave-per-pair / -couple kernels: 4, or 1 for small launches */
     uint32_t ldsEdge2Off;       /* ANW: offset of the second edge row (D) */
     uint32_t ldsRefOff;         /* offset of the staged reference characters */
     uint32_t ldsQryOff;         /* offset of the staged query characters (rolling multi-stripe path) */

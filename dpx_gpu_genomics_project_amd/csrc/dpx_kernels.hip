@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_fill(const dpx_fill
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* wave-uniform: everything per-pair lives in SGPRs */
+    int p = blockIdx.x * (int)a.wavesPerBlock + wv; /* wave-uniform: everything per-pair lives in SGPRs */
     if (p >= a.numPairs) return;
     if (a.order) p = a.order[p];
     const dpx_pair_dev pr = a.pairs[p];
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sidx = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* stream index (wave-uniform) */
+    const int sidx = blockIdx.x * (int)a.wavesPerBlock + wv; /* stream index (wave-uniform) */
     const int NW = a.numStreams;
     if (sidx >= NW || sidx >= a.numPairs) return;
     const int cnt = (a.numPairs - sidx + NW - 1) / NW; /* pairs of this stream */
@@ -1255,7 +1255,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS, DPX_PK_MIN_BLOCKS) k_linear_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* couple index */
+    const int c = blockIdx.x * (int)a.wavesPerBlock + wv; /* couple index */
     if (c >= a.numPairs) return;
     const int pA = a.order[2 * c], pB = a.order[2 * c + 1];
     const dpx_pair_dev prA = a.pairs[pA], prB = a.pairs[pB];
@@ -1886,7 +1886,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_affine_fill(const dpx_fill
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    int p = blockIdx.x * (int)a.wavesPerBlock + wv;
     if (p >= a.numPairs) return;
     if (a.order) p = a.order[p];
     const dpx_pair_dev pr = a.pairs[p];
@@ -2306,7 +2306,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill(const dpx_fill
     constexpr int GG = (G < 2) ? 2 : G;     /* steps per loop iteration (parity pattern repeats every 2) */
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int p = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    int p = blockIdx.x * (int)a.wavesPerBlock + wv;
     if (p >= a.numPairs) return;
     if (a.order) p = a.order[p];
     const dpx_pair_dev pr = a.pairs[p];
@@ -2477,7 +2477,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_banded_fill_pk(const dpx_f
     constexpr int GG = (G < 2) ? 2 : G;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cpl = blockIdx.x * (DPX_FILL_THREADS / 64) + wv; /* couple index */
+    const int cpl = blockIdx.x * (int)a.wavesPerBlock + wv; /* couple index */
     if (cpl >= a.numPairs) return;
     const int pA = a.order[2 * cpl], pB = a.order[2 * cpl + 1];
     const dpx_pair_dev prA = a.pairs[pA], prB = a.pairs[pB];
@@ -3249,7 +3249,10 @@ hipError_t launch_fill_kernel(K kernel, const dpx_fill_args &a, dim3 grid, size_
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, grid, dim3(DPX_FILL_THREADS), lds, s, a);
+    /* workgroups of a.wavesPerBlock independent waves (4, or 1 for small launches: see dpx_fill_waves_per_block); `lds` is the request of a
+     * four-wave workgroup */
+    const unsigned wpb = a.wavesPerBlock;
+    hipLaunchKernelGGL(kernel, grid, dim3(64u * wpb), lds / 4u * wpb, s, a);
     return hipGetLastError();
 }
 
@@ -3289,7 +3292,7 @@ hipError_t launch_affine_R(const dpx_fill_args &a, bool store, dim3 grid, size_t
 
 hipError_t dpx_launch_fill(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    const int wavesPerBlock = (int)a.wavesPerBlock;
     dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
     if (algo == DPX_K_LNW || algo == DPX_K_LSW) {
         const bool local = algo == DPX_K_LSW;
@@ -3410,7 +3413,7 @@ hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R,
 /* stream schedule (uniform batches): a.numStreams persistent waves, each fills its pairs back to back */
 hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0 || a.numStreams <= 0) return hipSuccess;
-    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    const int wavesPerBlock = (int)a.wavesPerBlock;
     dim3 grid((unsigned)((a.numStreams + wavesPerBlock - 1) / wavesPerBlock));
     const bool local = algo == DPX_K_LSW;
 #define DPX_STREAM_CASE(R_)                                                                                    \
@@ -3429,7 +3432,7 @@ hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_
 /* packed two-pairs-per-wave linear fill: a.order = couples (2 ints each), a.numPairs = number of couples */
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    const int wavesPerBlock = (int)a.wavesPerBlock;
     dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
     const bool local = algo == DPX_K_LSW;
     switch (R) {
@@ -3449,7 +3452,7 @@ static hipError_t launch_banded_pk_C(const dpx_fill_args &a, dim3 grid, size_t l
 }
 hipError_t dpx_launch_banded_packed(const dpx_fill_args &a, int C, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int wavesPerBlock = DPX_FILL_THREADS / 64;
+    const int wavesPerBlock = (int)a.wavesPerBlock;
     dim3 grid((unsigned)((a.numPairs + wavesPerBlock - 1) / wavesPerBlock));
     switch (C) {
     case 1: return launch_banded_pk_C<1>(a, grid, ldsBytes, stream);

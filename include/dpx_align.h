@@ -97,7 +97,7 @@ int dpx_device_count(int *count);
 int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBytes);
 int dpx_shutdown(void);
 /* Allocate `count` (1 or 2) matrix pools of `bytes` each on the default device and park them for the batches to come (any batch
- * whose matrices fit takes a parked pool instead of allocating).  Meant for a helper thread while the caller parses its input:
+ * whose matrices fit takes a parked pool instead of allocating), together with two streams per pool for those batches.  Meant for a helper thread while the caller parses its input:
  * the reference sizes its device buffers once, before the batch loop (cuda/LNW/LinearNeedlemanWunschV14.cu:144-213). */
 int dpx_pool_reserve(size_t bytes, int count);
 /* The same for `count` (1..4) pinned host buffers of `bytes` (<= 1 GiB) each, which the result text of the batches to come is copied
