@@ -1492,7 +1492,10 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         k.waves = reinterpret_cast<const dpx_wave_desc *>(b->dCouples);
         k.numPairs = (int32_t)waves.size();
         k.ldsPerWave = (uint32_t)(dpx_lanes_stage_bytes(kernelAlgo, kLanesR, b->store) + lanesRefArea);
-        b->pkLdsBytes = (size_t)k.ldsPerWave * (size_t)dpx_lanes_waves_per_block(kernelAlgo);
+        /* (the lane-packed kernels keep their four-wave workgroups at every size: 20 000 short reads 131-148 us against 150-153 with one-wave
+         * workgroups, 100 000 the same; DPX_WPB=1 forces the latter) */
+        k.wavesPerBlock = kernelAlgo == DPX_ALGO_ANW ? 1u : (getenv("DPX_WPB") && atoi(getenv("DPX_WPB")) == 1 ? 1u : (uint32_t)dpx_lanes_waves_per_block(kernelAlgo));
+        b->pkLdsBytes = (size_t)k.ldsPerWave * (size_t)k.wavesPerBlock;
         if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
@@ -1877,9 +1880,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
                          : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
-    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d seq_input=%s",
+    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d seq_input=%s waves_per_workgroup=%u",
                        names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
-                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes");
+                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes",
+                       (b->packed || b->lanePacked) ? b->pkArgs.wavesPerBlock : (b->split || b->splitPk) ? (unsigned)b->splitWaves : b->args.wavesPerBlock);
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;
         len += snprintf(buf + len, cap - (size_t)len, " pool=%s pool_bytes=%zu pool_chunk_mb=%zu pool_kept=%d pool_memset_ms=", r.mode.c_str(), b->matPoolBytes,

@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
     using Stage = LineStage<Q, 1>;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    const int w = blockIdx.x * (int)a.wavesPerBlock + wv;
     if (w >= a.numPairs) return; /* wave-uniform; numPairs = number of wave descriptors */
     const LaneSlot sl = find_slot(a.waves + w, lane);
     const bool has = sl.has;
@@ -1412,7 +1412,7 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
     constexpr int kStepElems = 1024;                 /* int16 elements of one chunk of the wave's stream (two 1-KiB halves) */
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * (DPX_FILL_THREADS / 64) + wv;
+    const int w = blockIdx.x * (int)a.wavesPerBlock + wv;
     if (w >= a.numPairs) return;
     const LaneSlot sl = find_slot(a.waves + w, lane);
     const bool has = sl.has;
@@ -3331,7 +3331,7 @@ size_t dpx_lanes_stage_bytes(int algo, int R, bool store) {
     if (!store) return (size_t)kLaneScratch;
     return (size_t)(algo == DPX_K_ANW ? 3 : 1) * (size_t)(R / 8) * 64u * (size_t)kStageLine;
 }
-int dpx_lanes_waves_per_block(int algo) { return algo == DPX_K_ANW ? DPX_ALANES_THREADS / 64 : DPX_FILL_THREADS / 64; }
+int dpx_lanes_waves_per_block(int algo) { return algo == DPX_K_ANW ? DPX_ALANES_THREADS / 64 : DPX_FILL_THREADS / 64; } /* (the most: small launches of the linear kernels use 1) */
 
 template <class K>
 static hipError_t launch_lanes_kernel(K kernel, const dpx_fill_args &a, dim3 grid, int threads, size_t lds, hipStream_t s) {
@@ -3345,7 +3345,7 @@ static hipError_t launch_lanes_kernel(K kernel, const dpx_fill_args &a, dim3 gri
 
 hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool store, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int wpb = dpx_lanes_waves_per_block(algo);
+    const int wpb = algo == DPX_K_ANW ? DPX_ALANES_THREADS / 64 : (int)a.wavesPerBlock; /* (ldsBytes = per wave x this) */
     dim3 grid((unsigned)((a.numPairs + wpb - 1) / wpb));
     if (algo == DPX_K_ANW) {
         const int th = DPX_ALANES_THREADS;
@@ -3354,7 +3354,7 @@ hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool s
         return hipErrorInvalidValue;
     }
     const bool local = algo == DPX_K_LSW;
-    const int th = DPX_FILL_THREADS;
+    const int th = 64 * wpb;
 #define DPX_LANES_CASE(R_)                                                                                              \
     case R_:                                                                                                           \
         if (local) return store ? launch_lanes_kernel(k_linear_lanes<R_, true, true>, a, grid, th, ldsBytes, stream)    \
@@ -3372,10 +3372,10 @@ hipError_t dpx_launch_fill_lanes(const dpx_fill_args &a, int algo, int R, bool s
 /* packed lane kernel (16 rows per lane, two row blocks of one pair in the two halves): a.waves / a.numPairs as dpx_launch_fill_lanes */
 hipError_t dpx_launch_fill_lanes_packed(const dpx_fill_args &a, int algo, size_t ldsBytes, hipStream_t stream) {
     if (a.numPairs <= 0) return hipSuccess;
-    const int wpb = DPX_FILL_THREADS / 64;
+    const int wpb = (int)a.wavesPerBlock;
     dim3 grid((unsigned)((a.numPairs + wpb - 1) / wpb));
-    return algo == DPX_K_LSW ? launch_lanes_kernel(k_linear_lanes_pk<true>, a, grid, DPX_FILL_THREADS, ldsBytes, stream)
-                             : launch_lanes_kernel(k_linear_lanes_pk<false>, a, grid, DPX_FILL_THREADS, ldsBytes, stream);
+    return algo == DPX_K_LSW ? launch_lanes_kernel(k_linear_lanes_pk<true>, a, grid, 64 * wpb, ldsBytes, stream)
+                             : launch_lanes_kernel(k_linear_lanes_pk<false>, a, grid, 64 * wpb, ldsBytes, stream);
 }
 
 /* split kernel (small batches): one workgroup of `waves` waves per pair, a.numPairs workgroups */

@@ -11,15 +11,18 @@ from dpx_gpu_genomics_project_amd.synth import from_strings, make_batch, make_ra
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "one-wave-per-pair", "one-wave-per-pair+ramp-lines"])
+@pytest.fixture(autouse=True, params=["default", "one-wave-per-pair", "one-wave-per-pair+ramp-lines", "one-wave-per-pair+four-wave-workgroups"])
 def kernel_path(request, monkeypatch):
-    """Every test of this file runs three times: with the engine's own choice (small multi-stripe batches take the split
-    kernel), with DPX_SPLIT=0 (the one-wave-per-pair kernels incl. their rolling multi-stripe schedule), and with the
-    line-rounded ramp stores big batches use (DPX_RAMP_LINES=1) forced onto these small ones."""
+    """Every test of this file runs four times: with the engine's own choice (small multi-stripe batches take the split
+    kernel), with DPX_SPLIT=0 (the one-wave-per-pair kernels incl. their rolling multi-stripe schedule), with the
+    line-rounded ramp stores big batches use (DPX_RAMP_LINES=1) forced onto these small ones, and with the four-wave
+    workgroups of launches of more than 4096 waves (DPX_WPB=4; small launches use one-wave workgroups)."""
     if request.param != "default":
         monkeypatch.setenv("DPX_SPLIT", "0")
     if request.param.endswith("ramp-lines"):
         monkeypatch.setenv("DPX_RAMP_LINES", "1")
+    if request.param.endswith("four-wave-workgroups"):
+        monkeypatch.setenv("DPX_WPB", "4")
     return request.param
 
 

@@ -14,13 +14,16 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(autouse=True, params=["packed-row-blocks", "int32-lanes"])
+@pytest.fixture(autouse=True, params=["packed-row-blocks", "int32-lanes", "packed-row-blocks+one-wave-workgroups"])
 def lanes_kernel(request, monkeypatch):
     """Round 3: where the weights allow it the linear lane-packed batches run on k_linear_lanes_pk (16 rows per lane, two row blocks
     of one pair in the halves of every register, the low half one column behind); DPX_LANES_PK=0 keeps the int32 kernels.  Every
     test of this file runs on both."""
     if request.param == "int32-lanes":
         monkeypatch.setenv("DPX_LANES_PK", "0")
+    if request.param.endswith("one-wave-workgroups"):  # (an experiment knob: the lane-packed kernels ship with four-wave workgroups)
+        monkeypatch.setenv("DPX_WPB", "1")
+        return "packed-row-blocks"
     return request.param
 
 

@@ -11,7 +11,7 @@ from dpx_gpu_genomics_project_amd.synth import make_ragged_batch  # noqa: E402
 dpx.init(0)
 for name in ("LNW", "LSW"):
     algo = {"LSW": dpx.ALGO_LSW, "LNW": dpx.ALGO_LNW}[name]
-    for count in (25000, 50000, 100000, 200000, 400000):
+    for count in ([int(x) for x in sys.argv[1:]] or [25000, 50000, 100000, 200000, 400000]):
         sb = make_ragged_batch(count, 80, 130, 100, 160, seed=6)
         with dpx.Batch(algo, sb.sequences, sb.pairs, 3, -1, -2) as b:
             d = b.describe()
