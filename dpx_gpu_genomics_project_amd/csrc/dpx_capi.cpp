@@ -743,7 +743,7 @@ static uint32_t fill_waves_per_block(size_t waves) {
  * next while hipMemset sees no difference; LSW 10k x 1024^2: +-2 %; tools/mode_watch.py, profiles/r03/): the mode belongs to the
  * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: five
  * candidate pools of different constructions (see below), one warm-up + three timed fills each, the fastest is kept (and parked for
- * later batches), the loser of every comparison is freed at once (never more than two pools alive).  Every candidate's
+ * later batches), the losers are freed together when the last candidate has been timed.  Every candidate's
  * construction and times go into the pool record (dpx_batch_describe -> bench.py roofline.pool). */
 static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -775,6 +775,11 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
      * more of them, as before). */
     const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB");
     const long long builds[4] = {forced ? 0 : (long long)1 << 30, forced ? 0 : (long long)2 << 30, forced ? 0 : (long long)512 << 20, 0};
+    /* NO pool is unmapped before the last candidate has been filled: the losers are freed together at the end (memory permitting -- the
+     * loop stops when the next candidate would not leave 8 GiB free).  One run of this loop that freed every loser at once (so that the
+     * next candidate could be mapped at the address range just given back) ended in a GPU memory access fault during a candidate's four
+     * fills under rocprofv3 (profiles/r03/gpu_fault_while_shopping.txt; one in ~40 runs, never seen with one construction). */
+    std::vector<void *> losers;
     float lo = bestMs, hi = bestMs;
     for (int k = 1; k < (forced ? 4 : 5) && bestMs > 0.f; k++) {
         if (forced && k >= 2 && hi > lo * 1.03f) break; /* both modes of one construction seen */
@@ -792,10 +797,12 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
         rec.kinds.push_back(kind_of(built.mode, built.chunkBytes));
         rec.candidatesMs.push_back(time_memset(cand, bytes, b->stream));
         if (ms > 0.f) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
-        if (ms > 0.f && ms < bestMs) { pool_free(best); best = cand; bestMs = ms; rec.kept = k; rec.mode = built.mode; rec.chunkBytes = built.chunkBytes; }
-        else pool_free(cand);
+        if (ms > 0.f && ms < bestMs) { losers.push_back(best); best = cand; bestMs = ms; rec.kept = k; rec.mode = built.mode; rec.chunkBytes = built.chunkBytes; }
+        else losers.push_back(cand);
     }
     set_pool(best);
+    (void)hipStreamSynchronize(b->stream);
+    for (void *p : losers) pool_free(p);
     if (trace.on) for (size_t k = 0; k < rec.fillMs.size(); k++) fprintf(stderr, "[dpx] pool candidate %zu (%s): fill %.3f ms%s\n", k, rec.kinds[k].c_str(), rec.fillMs[k], (int)k == rec.kept ? "  <- kept" : "");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
