@@ -373,6 +373,7 @@ struct dpx_batch {
     bool filled = false;
     uint64_t cells = 0, matElems = 0, algBytes = 0, bandCells = 0;
     size_t matPoolBytes = 0; /* bytes of the block behind dMat (may exceed matElems*2 when a parked pool was reused) */
+    size_t guardBytes = 0;   /* DPX_POOL_GUARD: pattern bytes behind the matrices, checked by dpx_batch_sync() */
     int maxN = 0, maxM = 0;
     std::vector<dpx_pair_dev> pairs; /* host mirror of the device pair table */
     char *dSeq = nullptr;
@@ -1391,7 +1392,14 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     if (b->store && b->matElems) {
         void *pool = nullptr;
         bool fresh = false;
-        CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t), &b->matPoolBytes, &fresh));
+        /* DPX_POOL_GUARD=1 (tests): 4 MiB behind the matrices are filled with a pattern here and checked by dpx_batch_sync() -- a kernel that
+         * writes past the end of the batch's matrices fails the test instead of hitting whatever is mapped behind the pool */
+        const bool guardOn = getenv("DPX_POOL_GUARD") != nullptr;
+        b->guardBytes = guardOn ? (size_t)4 << 20 : 0;
+        CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t) + b->guardBytes, &b->matPoolBytes, &fresh));
+        if (b->guardBytes) CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t), 0xA5, b->guardBytes));
+        if (b->guardBytes && !strcmp(getenv("DPX_POOL_GUARD"), "selftest")) /* (the checker's own test: one byte of the band is already wrong) */
+            CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t) + 12345, 0, 1));
         /* DPX_TUNE_PLACEMENT (callers that fill the batch many times): the pool is timed with hipMemset and, if it is a fresh one,
          * shopped for with the batch's own fill at the end of this function (shop_pool_by_fill: up to three more allocations of the
          * pool's size).  DPX_POOL_PROBE=0 / 1 / 2 forces nothing / timing only / timing + shopping, whatever the flag says */
@@ -1526,7 +1534,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     b->nCouples = (b->packed || b->splitPk) ? numCouples : 0;
     b->nLanePairs = b->lanePacked ? lanesPairs : 0;
     b->nWaves = b->lanePacked ? waves.size() : 0;
-    if (b->tuneShop && b->dMat) {
+    if (b->tuneShop && b->dMat && !b->guardBytes) {
         shop_pool_by_fill(b, b->poolRec, trace);
         std::lock_guard<std::mutex> lk(g_poolRecMu);
         g_poolRecords[b->dMat] = b->poolRec;
@@ -1659,6 +1667,12 @@ int dpx_batch_sync(dpx_batch *b) {
     if (rc != DPX_OK) return rc;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->guardBytes && b->dMat) { /* DPX_POOL_GUARD: nothing may have written behind the matrices */
+        std::vector<unsigned char> h(b->guardBytes);
+        HIP_TRY(hipMemcpy(h.data(), (const char *)b->dMat + b->matElems * sizeof(int16_t), b->guardBytes, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < h.size(); k++)
+            if (h[k] != 0xA5) { t_err = "DPX_POOL_GUARD: byte " + std::to_string(k) + " behind the matrices was overwritten"; return DPX_ERR_HIP; }
+    }
     return DPX_OK;
 }
 
