@@ -774,7 +774,11 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
      * 1-GiB, 2-GiB and 512-MiB chunks, then the first construction once more (one hipMalloc, like one chunk for the whole pool, never
      * won: 3.58-3.7 ms everywhere).  With DPX_POOL / DPX_POOL_CHUNK_MB set every candidate is built the way they say (up to three
      * more of them, as before). */
-    const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB");
+    /* ... but comparing constructions is OPT-IN (DPX_POOL_SHOP_KINDS=1): twice in ~60 runs a process died with a GPU memory access fault
+     * while a candidate built from 512-MiB / 1-GiB / 2-GiB chunks was being filled (profiles/r03/gpu_fault_while_shopping.txt), never
+     * in hundreds of runs on 256-MiB chunks.  Without the knob every candidate is built like the first one. */
+    const bool kindsOn = [] { const char *e = getenv("DPX_POOL_SHOP_KINDS"); return e && atoi(e) != 0; }();
+    const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB") || !kindsOn;
     const long long builds[4] = {forced ? 0 : (long long)1 << 30, forced ? 0 : (long long)2 << 30, forced ? 0 : (long long)512 << 20, 0};
     /* NO pool is unmapped before the last candidate has been filled: the losers are freed together at the end (memory permitting -- the
      * loop stops when the next candidate would not leave 8 GiB free).  One run of this loop that freed every loser at once (so that the

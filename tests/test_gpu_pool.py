@@ -52,13 +52,12 @@ def test_tuned_placement_records_every_candidate(gpu):
     d, res, _ = _fill(gpu, sb, flags=gpu.TUNE_PLACEMENT)
     fills = [float(x) for x in str(d["pool_fill_ms"]).split(",")]
     sets = [float(x) for x in str(d["pool_memset_ms"]).split(",")]
-    assert 1 <= len(fills) <= 5 and len(sets) == len(fills) and 0 <= d["pool_kept"] < len(fills)
+    assert 1 <= len(fills) <= 4 and len(sets) == len(fills) and 0 <= d["pool_kept"] < len(fills)
     assert all(0.05 < f < 50 for f in fills) and fills[d["pool_kept"]] == min(fills)
-    # the candidates differ in construction: 256-MiB chunks (the default), 1-GiB, 2-GiB and 512-MiB chunks, the default again
+    # every candidate is built like the first one (256-MiB chunks); other constructions are opt-in (DPX_POOL_SHOP_KINDS=1: two GPU
+    # memory access faults in ~60 runs while candidates of 512-MiB / 1-GiB / 2-GiB chunks were being filled -- never exercised here)
     kinds = str(d["pool_kinds"]).split(",")
-    assert kinds == ["vmm256", "vmm1024", "vmm2048", "vmm512", "vmm256"] and len(fills) == 5
-    kept = kinds[d["pool_kept"]]
-    assert (d["pool"], d["pool_chunk_mb"]) == (("malloc", 0) if kept == "malloc" else ("vmm", int(kept[3:])))
+    assert kinds == ["vmm256"] * len(fills) and (d["pool"], d["pool_chunk_mb"]) == ("vmm", 256)
     d2, res2, _ = _fill(gpu, sb, flags=gpu.TUNE_PLACEMENT)       # the parked pool comes back with its record, nothing is re-timed
     assert d2["pool_fill_ms"] == d["pool_fill_ms"] and d2["pool_memset_ms"] == d["pool_memset_ms"]
     assert all(np.array_equal(x, y) for x, y in zip(res, res2))
