@@ -74,7 +74,7 @@ typedef struct dpx_params {
 #define DPX_SCORE_ONLY    0x1u /* no matrix writeback (not HBM-bound; never used for the roofline figure) */
 #define DPX_TIME_FILLS    0x2u /* bracket every dpx_batch_fill() with HIP events: dpx_batch_last_fill_usec() */
 #define DPX_TUNE_PLACEMENT 0x4u /* the batch will be filled many times: time its matrix pool (>= 1 GiB) with hipMemset and shop for a better
-                                   one with the batch's OWN FILL on up to three more candidate pools (the same fill runs 2 - 27 % apart on
+                                   one with the batch's OWN FILL on four more candidate pools (the same fill runs 2 - 27 % apart on
                                    two pools of the same construction); every candidate's times go into dpx_batch_describe's pool_* fields */
 
 /* matrix selectors for dpx_batch_matrix */

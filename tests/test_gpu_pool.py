@@ -52,7 +52,7 @@ def test_tuned_placement_records_every_candidate(gpu):
     d, res, _ = _fill(gpu, sb, flags=gpu.TUNE_PLACEMENT)
     fills = [float(x) for x in str(d["pool_fill_ms"]).split(",")]
     sets = [float(x) for x in str(d["pool_memset_ms"]).split(",")]
-    assert 1 <= len(fills) <= 4 and len(sets) == len(fills) and 0 <= d["pool_kept"] < len(fills)
+    assert 1 <= len(fills) <= 5 and len(sets) == len(fills) and 0 <= d["pool_kept"] < len(fills)
     assert all(0.05 < f < 50 for f in fills) and fills[d["pool_kept"]] == min(fills)
     # every candidate is built like the first one (256-MiB chunks); other constructions are opt-in (DPX_POOL_SHOP_KINDS=1: two GPU
     # memory access faults in ~60 runs while candidates of 512-MiB / 1-GiB / 2-GiB chunks were being filled -- never exercised here)
