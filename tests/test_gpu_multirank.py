@@ -75,11 +75,13 @@ def test_bench_three_ranks_strong_scaling_shards(tmp_path):
             assert gathered[lo + p] == O.lsw(sb.ref(p), sb.qry(p), *W, want_dir=False).score, (r, p)
 
 
-def test_config4_one_rank_shard_of_lsw_100k_1024_at_full_size(gpu):
-    """Rank 5 of 8 of BASELINE.json's configs[4]: shard_range(100000, 5, 8) = 12 500 pairs of 1024 x 1024, 27.8 GB of H."""
-    rank, world = 5, 8
+@pytest.mark.parametrize("rank", [0, 5, 7])
+def test_config4_one_rank_shard_of_lsw_100k_1024_at_full_size(gpu, rank):
+    """Ranks 0, 5 and 7 of 8 of BASELINE.json's configs[4] (round 2: rank 5 only): shard_range(100000, rank, 8) = 12 500 pairs of
+    1024 x 1024, 27.8 GB of H."""
+    world = 8
     lo, hi = shard_range(100000, rank, world)
-    assert (lo, hi) == (62500, 75000)
+    assert (lo, hi) == (12500 * rank, 12500 * (rank + 1))
     sb = make_batch(hi - lo, 1024, 1024, seed=5 + 1000 * rank, first_index=lo)   # what bench.py builds on that rank
     with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *W) as b:
         d, info = b.describe(), b.info()
