@@ -374,6 +374,7 @@ struct dpx_batch {
     uint64_t cells = 0, matElems = 0, algBytes = 0, bandCells = 0;
     size_t matPoolBytes = 0; /* bytes of the block behind dMat (may exceed matElems*2 when a parked pool was reused) */
     size_t guardBytes = 0;   /* DPX_POOL_GUARD: pattern bytes behind the matrices, checked by dpx_batch_sync() */
+    bool guardSelfTest = false;
     int maxN = 0, maxM = 0;
     std::vector<dpx_pair_dev> pairs; /* host mirror of the device pair table */
     char *dSeq = nullptr;
@@ -813,6 +814,8 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
+static int check_guard(dpx_batch *b);
+
 int dpx_batch_destroy(dpx_batch *b) {
     if (!b) return DPX_OK;
     PhaseTrace trace;
@@ -821,6 +824,7 @@ int dpx_batch_destroy(dpx_batch *b) {
     if (b->lastStream && b->lastStream != b->stream) (void)hipStreamSynchronize(b->lastStream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); stream_park(b->stream); }
     if (b->sideStream) { (void)hipStreamSynchronize(b->sideStream); stream_park(b->sideStream); }
+    if (b->guardBytes && !b->guardSelfTest && check_guard(b) != DPX_OK) { fprintf(stderr, "[dpx] %s\n", t_err.c_str()); abort(); }
     if (b->evT0) (void)hipEventDestroy(b->evT0);
     if (b->evT1) (void)hipEventDestroy(b->evT1);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
@@ -1403,8 +1407,10 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         b->guardBytes = guardOn ? (size_t)4 << 20 : 0;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t) + b->guardBytes, &b->matPoolBytes, &fresh));
         if (b->guardBytes) CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t), 0xA5, b->guardBytes));
-        if (b->guardBytes && !strcmp(getenv("DPX_POOL_GUARD"), "selftest")) /* (the checker's own test: one byte of the band is already wrong) */
+        if (b->guardBytes && !strcmp(getenv("DPX_POOL_GUARD"), "selftest")) { /* (the checker's own test: one byte of the band is already wrong) */
             CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t) + 12345, 0, 1));
+            b->guardSelfTest = true;
+        }
         /* DPX_TUNE_PLACEMENT (callers that fill the batch many times): the pool is timed with hipMemset and, if it is a fresh one,
          * shopped for with the batch's own fill at the end of this function (shop_pool_by_fill: four more allocations of the
          * pool's size).  DPX_POOL_PROBE=0 / 1 / 2 forces nothing / timing only / timing + shopping, whatever the flag says */
@@ -1423,7 +1429,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
             rec.chunkBytes = t_poolStats.chunkBytes;
             rec.bytes = b->matPoolBytes;
         }
-        b->tunePool = tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30);
+        b->tunePool = tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30) && !b->guardBytes; /* (the memset probe would wipe the band) */
         b->tuneShop = b->tunePool && fresh && probeEnv != 1; /* DPX_POOL_PROBE=1: time only, no shopping */
         if (b->tunePool) rec.candidatesMs.assign(1, time_memset(pool, b->matPoolBytes, b->stream));
         b->dMat = (int16_t *)pool;
@@ -1666,19 +1672,24 @@ int dpx_batch_fill_timed(dpx_batch *b, int repeats, double *usecPerFill) {
     return DPX_OK;
 }
 
+/* DPX_POOL_GUARD: nothing may have written behind the matrices (checked by dpx_batch_sync, dpx_batch_results and -- fatally, so that a
+ * whole test run under the knob cannot miss it -- by dpx_batch_destroy) */
+static int check_guard(dpx_batch *b) {
+    if (!b->guardBytes || !b->dMat) return DPX_OK;
+    std::vector<unsigned char> h(b->guardBytes);
+    HIP_TRY(hipMemcpy(h.data(), (const char *)b->dMat + b->matElems * sizeof(int16_t), b->guardBytes, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < h.size(); k++)
+        if (h[k] != 0xA5) { t_err = "DPX_POOL_GUARD: byte " + std::to_string(k) + " behind the matrices was overwritten"; return DPX_ERR_HIP; }
+    return DPX_OK;
+}
+
 int dpx_batch_sync(dpx_batch *b) {
     if (!b) return DPX_ERR_INVALID;
     int rc = bind_device(b->device);
     if (rc != DPX_OK) return rc;
     if (b->lastStream && b->lastStream != b->stream) HIP_TRY(hipStreamSynchronize(b->lastStream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    if (b->guardBytes && b->dMat) { /* DPX_POOL_GUARD: nothing may have written behind the matrices */
-        std::vector<unsigned char> h(b->guardBytes);
-        HIP_TRY(hipMemcpy(h.data(), (const char *)b->dMat + b->matElems * sizeof(int16_t), b->guardBytes, hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < h.size(); k++)
-            if (h[k] != 0xA5) { t_err = "DPX_POOL_GUARD: byte " + std::to_string(k) + " behind the matrices was overwritten"; return DPX_ERR_HIP; }
-    }
-    return DPX_OK;
+    return check_guard(b);
 }
 
 int dpx_batch_device_results(dpx_batch *b, void **dScores, void **dEndRow, void **dEndCol) {
@@ -1702,7 +1713,7 @@ int dpx_batch_results(dpx_batch *b, int32_t *scores, int32_t *endRow, int32_t *e
         if (endRow) HIP_TRY(hipMemcpy(endRow, b->dEndRow, bytes, hipMemcpyDeviceToHost));
         if (endCol) HIP_TRY(hipMemcpy(endCol, b->dEndCol, bytes, hipMemcpyDeviceToHost));
     }
-    return DPX_OK;
+    return check_guard(b);
 }
 
 int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
