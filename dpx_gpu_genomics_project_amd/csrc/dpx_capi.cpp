@@ -1785,7 +1785,11 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         int walk = b->numPairs >= 65536 ? 1 : 0;
         /* long paths on layouts with 8-row column vectors: one wave per pair through an LDS window, one HBM round trip per ~32
          * path steps instead of one per step (round 2: 5000 x 1024^2 LSW 1.60 vs 1.83 ms; loses below ~1000-step paths) */
-        if (b->maxM + b->maxN >= wave_walk_min_path() && b->numPairs < 65536 && b->kernelAlgo != DPX_ALGO_BSW) walk = 2;
+        /* (tools/tb_time.py p512, traceback + D2H of the lines, wave vs lane walk: 1000 x 512^2 0.49 vs 0.90 ms LSW, 0.60 vs 1.24 ANW; 4000 x 512^2
+         * 0.81 vs 1.09, 1.33 vs 1.40; 3000 x 700^2 0.96 vs 1.39; but 20 000 x 300^2 2.05 vs 1.64: from 900-step paths on, up to 16k pairs) */
+        if (b->kernelAlgo != DPX_ALGO_BSW &&
+            ((b->maxM + b->maxN >= wave_walk_min_path() && b->numPairs < 65536) ||
+             (!getenv("DPX_TB_WAVE_MIN") && b->maxM + b->maxN >= 900 && b->numPairs < 16384))) walk = 2;
         if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
         else if (const char *env = getenv("DPX_TB_CACHED")) walk = atoi(env) != 0 ? 1 : 0; /* (round-1 knob, tests) */
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));

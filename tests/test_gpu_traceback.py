@@ -77,7 +77,7 @@ def test_banded_traceback_vs_oracle(gpu):
 def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
     """Three ways to walk (DPX_TB_WALK forces one): 0 = one lane per pair, cell by cell; 1 = one lane per pair through register-
     cached 8-row column vectors (chosen for batches of >= 65536 pairs); 2 = one wave per pair with an LDS window of 32 rows x 64
-    columns and a scalar walker (chosen for batches whose paths are long, m + n >= 1500; 0 otherwise).  8- and 16-row tiles, several stripes, lane-group, stripe and window crossings, the lane-packed tile
+    columns and a scalar walker (chosen for batches whose paths are long: m + n >= 1500, or >= 900 in batches of up to 16k pairs; 0 otherwise).  8- and 16-row tiles, several stripes, lane-group, stripe and window crossings, the lane-packed tile
     layout, the split layout, borders reached from both sides, empty sequences -- every printed line
     against the oracle."""
     monkeypatch.setenv("DPX_TB_WALK", cached)
@@ -106,7 +106,7 @@ def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
 @pytest.mark.parametrize("walk", ["0", "2"])
 @pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
 def test_wave_walk_on_every_layout(gpu, algo, walk, monkeypatch):
-    """Round 3: the wave walk (one wave per pair, scalar walker over an LDS window; chosen for every batch with m + n >= 1500) reads
+    """Round 3: the wave walk (one wave per pair, scalar walker over an LDS window; chosen for every batch with m + n >= 1500, and from 900 on in batches of up to 16k pairs) reads
     every matrix layout -- wavefront-tiled with 2, 4, 8 and 16 rows per lane, the split layout (2 and 4 rows per lane: an 8-row group
     is assembled from the pieces of 2 or 4 lanes), the lane-packed tile layout with one and with three planes -- and walks the affine
     three-state path too.  Every printed line against the oracle, forced (DPX_TB_WALK) on short and long paths alike."""

@@ -8,6 +8,10 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 shapes = []
 if which in ("both", "long"):
     shapes.append(("5000 x 1024x1024", dpx.make_batch(5000, 1024, 1024, seed=1)))
+if which in ("p512",):
+    shapes.append(("4000 x 512x512", dpx.make_batch(4000, 512, 512, seed=1)))
+    shapes.append(("1000 x 512x512", dpx.make_batch(1000, 512, 512, seed=1)))
+    shapes.append(("3000 x 700x700", dpx.make_batch(3000, 700, 700, seed=1)))
 if which in ("both", "mid"):
     shapes.append(("20000 x 300x300", dpx.make_batch(20000, 300, 300, seed=1)))
 if which in ("both", "short"):
