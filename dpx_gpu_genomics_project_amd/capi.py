@@ -232,8 +232,8 @@ class Batch:
 
     def describe(self) -> dict:
         """How the engine fills this batch (dpx_batch_describe): kernel, arithmetic type, launch-list sizes."""
-        buf = C.create_string_buffer(1024)
-        _check(self._lib.dpx_batch_describe(self._h, buf, 1024), "dpx_batch_describe")
+        buf = C.create_string_buffer(2048)
+        _check(self._lib.dpx_batch_describe(self._h, buf, 2048), "dpx_batch_describe")
         out = dict(kv.split("=", 1) for kv in buf.value.decode().split())
         return {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in out.items()}
 

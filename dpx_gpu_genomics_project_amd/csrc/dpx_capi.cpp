@@ -78,57 +78,97 @@ constexpr size_t kLdsFloor = 36u * 1024u * (DPX_FILL_THREADS / 64) / 4;
  * So every matrix pool of every caller is a chunked virtual range of 256-MiB chunks (DPX_POOL=malloc restores hipMalloc for
  * A/B runs; DPX_POOL_CHUNK_MB sets the chunk size).  Small pools (< 64 MiB) stay on hipMalloc: the class-per-pair drivers create
  * thousands of them. */
-struct VmmRange { size_t bytes; int device; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks; };
+struct VmmRange {
+    size_t bytes; int device; size_t chunkBytes;
+    void *reserved; size_t reservedBytes; /* what hipMemAddressReserve returned (the pool starts at the first chunk-aligned address inside) */
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
+};
 std::mutex g_vmmMu;
 std::map<void *, VmmRange> g_vmmRanges;
-struct PoolStats { const char *mode = "malloc"; size_t chunkBytes = 0; }; /* what the last pool_alloc of this thread did */
-thread_local PoolStats t_poolStats;
-/* how the next pool_alloc of this thread builds its pool (shop_pool_by_fill compares constructions): 0 = the default (256-MiB chunks,
- * or what DPX_POOL / DPX_POOL_CHUNK_MB say), > 0 = chunks of this many bytes, -1 = one hipMalloc */
-thread_local long long t_poolBuild = 0;
+void forget_pool_record(void *pool);
 
-/* Tearing a range down: ROCm 7.2 crashed inside hipMemAddressFree in about half the runs of the pool tests (shopping for a pool
- * builds and drops candidates next to a live one; native backtrace + call trace: profiles/r03/vmm_address_free_crash.txt), and with
- * one hipMemUnmap over the whole range the chunks behind the first stayed allocated.  What holds: wait for the device, undo every
- * mapping with the range it was made with, release the handles, wait again, free the address range -- ten of ten runs clean,
- * tools/pool_leak.py gets every byte back. */
-void vmm_release(void *va, const VmmRange &r, size_t mappedBytes) {
+/* Allocation granularity of device memory behind the virtual-memory API, queried once per device (round 4; rounds 1-3 assumed 2 MiB):
+ * every chunk size, every mapping offset and the reserved range are multiples of the RECOMMENDED granularity, and the range is reserved
+ * with the chunk size as its alignment, so a chunk never straddles a boundary of its own size. */
+size_t vmm_granularity(int device) {
+    static std::mutex mu;
+    static std::map<int, size_t> known;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gmin = 0, grec = 0;
+    if (hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum) != hipSuccess) { (void)hipGetLastError(); gmin = 0; }
+    if (hipMemGetAllocationGranularity(&grec, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) { (void)hipGetLastError(); grec = 0; }
+    size_t g = std::max<size_t>({gmin, grec, (size_t)2 << 20});
+    while (g & (g - 1)) g += g & (~g + 1); /* up to a power of two (it is one on every runtime seen) */
+    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] device %d: allocation granularity minimum %zu recommended %zu -> %zu\n", device, gmin, grec, g); fflush(stderr); }
+    known[device] = g;
+    return g;
+}
+
+/* Tearing a range down.  ROCm 7.2 crashed inside hipMemAddressFree (SIGSEGV in libamdhip64, profiles/r03/vmm_address_free_crash.txt) when
+ * a range was dropped with ONE hipMemUnmap over all of it: the runtime keeps one mapping object per hipMemMap call, an unmap that does
+ * not match one of them leaves the other mappings (and their physical chunks) alive, and hipMemAddressFree then walks a range that still
+ * holds live mappings.  So the load-bearing step is the per-chunk unmap: every mapping is undone with exactly the (address, size) it was
+ * made with, then its handle is released, and only then is the address range given back.  The device is idle before the first unmap
+ * (no kernel may still write the range); the second wait of rounds 3 (between release and address free) was belt and braces and is
+ * gone.  Every status is checked: on a failure the range stays in g_vmmRanges (nothing is double-freed, the leak is visible) and the
+ * error is left in dpx_last_error(). */
+bool vmm_release(void *va, VmmRange &r, size_t mappedBytes) {
     static const bool dbg = getenv("DPX_TRACE_VMM") != nullptr;
-    if (dbg) { fprintf(stderr, "[vmm] release %p bytes %zu mapped %zu chunks %zu: unmap\n", va, r.bytes, mappedBytes, r.chunks.size()); fflush(stderr); }
+    if (dbg) { fprintf(stderr, "[vmm] release [%p, %p) mapped %zu chunks %zu\n", va, (void *)((char *)va + r.bytes), mappedBytes, r.chunks.size()); fflush(stderr); }
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (r.device >= 0 && r.device != cur) (void)hipSetDevice(r.device); /* (one process may drive several devices: wait for the range's own) */
-    (void)hipDeviceSynchronize();
-    { /* every mapping is undone with the range it was made with */
-        size_t off = 0;
-        for (const auto &c : r.chunks) {
-            if (off + c.second <= mappedBytes) (void)hipMemUnmap((char *)va + off, c.second);
-            off += c.second;
-        }
+    hipError_t bad = hipDeviceSynchronize();
+    const char *where = "hipDeviceSynchronize";
+    size_t off = 0;
+    for (auto &c : r.chunks) {
+        if (bad == hipSuccess && off + c.second <= mappedBytes) { bad = hipMemUnmap((char *)va + off, c.second); where = "hipMemUnmap"; }
+        off += c.second;
     }
-    if (dbg) { fprintf(stderr, "[vmm] handles\n"); fflush(stderr); }
-    for (const auto &c : r.chunks) (void)hipMemRelease(c.first);
-    (void)hipDeviceSynchronize();
-    (void)hipMemAddressFree(va, r.bytes);
-    if (dbg) { fprintf(stderr, "[vmm] done\n"); fflush(stderr); }
-    (void)hipGetLastError();
+    for (auto &c : r.chunks) {
+        if (bad != hipSuccess) break;
+        bad = hipMemRelease(c.first);
+        where = "hipMemRelease";
+    }
+    if (bad == hipSuccess) { bad = hipMemAddressFree(r.reserved, r.reservedBytes); where = "hipMemAddressFree"; }
+    if (bad != hipSuccess) {
+        t_err = std::string("matrix pool teardown: ") + where + ": " + hipGetErrorString(bad);
+        if (dbg) { fprintf(stderr, "[vmm] %s\n", t_err.c_str()); fflush(stderr); }
+        (void)hipGetLastError();
+    } else if (dbg) { fprintf(stderr, "[vmm] done\n"); fflush(stderr); }
     if (r.device >= 0 && r.device != cur && cur >= 0) (void)hipSetDevice(cur);
+    return bad == hipSuccess;
 }
 
 hipError_t pool_alloc(void **out, size_t bytes) {
     /* (read on every call, not cached: tools/pool_ab.py alternates the variants inside one process; a pool is allocated once per batch size) */
     const bool useMalloc = [] { const char *e = getenv("DPX_POOL"); return e && !strcmp(e, "malloc"); }();
     const size_t chunkEnv = [] { const char *e = getenv("DPX_POOL_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
-    t_poolStats = PoolStats();
-    if ((t_poolBuild == 0 ? useMalloc : t_poolBuild < 0) || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
-    const size_t gran = (size_t)2 << 20;
-    const size_t chunk = align_up(t_poolBuild > 0 ? (size_t)t_poolBuild : chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
+    if (useMalloc || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
+    const size_t gran = vmm_granularity(t_device);
+    size_t chunk = std::max(chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
+    while (chunk & (chunk - 1)) chunk += chunk & (~chunk + 1); /* a power of two >= the granularity: it is the alignment of the reserved range */
     VmmRange r;
     r.bytes = align_up(bytes, gran);
     r.device = t_device;
-    void *va = nullptr;
-    hipError_t e = hipMemAddressReserve(&va, r.bytes, 0, nullptr, 0);
+    r.chunkBytes = chunk;
+    /* hipMemAddressReserve of ROCm 7.2 ignores its alignment argument (ranges come back 2-MiB aligned whatever is asked for:
+     * profiles/r04/vmm_granularity_and_alignment.txt), so the range is reserved one chunk longer and the pool starts at the first
+     * chunk-aligned address inside it: every chunk is mapped at a multiple of its own size */
+    size_t align = chunk;
+    if (const char *env = getenv("DPX_POOL_ALIGN_MB")) { const long v = atol(env); if (v > 0) { align = std::max((size_t)v << 20, gran); while (align & (align - 1)) align += align & (~align + 1); } }
+    r.reservedBytes = r.bytes + align;
+    r.reserved = nullptr;
+    hipError_t e = hipMemAddressReserve(&r.reserved, r.reservedBytes, align, nullptr, 0);
     if (e != hipSuccess) { (void)hipGetLastError(); return hipMalloc(out, bytes); }
+    void *va = (void *)align_up((size_t)(uintptr_t)r.reserved, align);
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof prop);
     prop.type = hipMemAllocationTypePinned;
@@ -136,7 +176,7 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     prop.location.id = t_device;
     size_t mapped = 0;
     for (size_t off = 0; off < r.bytes && e == hipSuccess; off += chunk) {
-        const size_t sz = std::min(chunk, r.bytes - off);
+        const size_t sz = std::min(chunk, r.bytes - off); /* (the last one: a multiple of the granularity, like r.bytes) */
         hipMemGenericAllocationHandle_t h;
         e = hipMemCreate(&h, sz, &prop, 0);
         if (e != hipSuccess) break;
@@ -154,22 +194,28 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     }
     if (e != hipSuccess) {
         if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] building %p failed after %zu of %zu bytes mapped: %s\n", va, mapped, r.bytes, hipGetErrorString(e)); fflush(stderr); }
-        vmm_release(va, r, mapped);
+        (void)vmm_release(va, r, mapped);
         if (e == hipErrorOutOfMemory) return e;
         /* a runtime without (working) virtual-memory management: one hipMalloc, as before round 3 -- slower to write, never wrong */
         (void)hipGetLastError();
         return hipMalloc(out, bytes);
     }
-    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] alloc %p bytes %zu chunks %zu\n", va, r.bytes, r.chunks.size()); fflush(stderr); }
+    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] alloc [%p, %p) chunks %zu of %zu MiB\n", va, (void *)((char *)va + r.bytes), r.chunks.size(), chunk >> 20); fflush(stderr); }
     { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(va, std::move(r)); }
-    t_poolStats.mode = "vmm";
-    t_poolStats.chunkBytes = chunk;
     *out = va;
     return hipSuccess;
 }
 
+/* how the pool at `p` was built: chunk size of a virtual range, 0 for one hipMalloc */
+size_t pool_chunk_bytes(void *p) {
+    std::lock_guard<std::mutex> lk(g_vmmMu);
+    auto it = g_vmmRanges.find(p);
+    return it == g_vmmRanges.end() ? 0 : it->second.chunkBytes;
+}
+
 void pool_free(void *p) {
     if (!p) return;
+    forget_pool_record(p); /* (a later pool at the same address must not inherit this one's timings) */
     VmmRange r;
     bool found = false;
     {
@@ -177,8 +223,8 @@ void pool_free(void *p) {
         auto it = g_vmmRanges.find(p);
         if (it != g_vmmRanges.end()) { r = std::move(it->second); g_vmmRanges.erase(it); found = true; }
     }
-    if (found) vmm_release(p, r, r.bytes);
-    else (void)hipFree(p);
+    if (!found) { (void)hipFree(p); return; }
+    if (!vmm_release(p, r, r.bytes)) { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(p, std::move(r)); } /* kept: see vmm_release */
 }
 
 class BufCache {
@@ -222,7 +268,8 @@ hipError_t BufCache::take(void **out, size_t need, size_t *actual, bool *fresh) 
             /* (a parked matrix pool of up to 13 GiB serves any smaller batch: a driver that cuts a file into batches of one pool
              * budget ends with a short batch, and a pool reserved ahead of time -- dpx_pool_reserve -- is sized by the budget) */
             /* (a parked pinned buffer of up to 32 MiB -- dpx_text_reserve -- serves any smaller text) */
-            const size_t roof = kind_ == DevicePool ? std::max(need + need / 2 + (1u << 20), (size_t)13 << 30)
+            /* (... but not a tiny one: the class-per-pair drivers create thousands of batches of a few MiB, which stay on hipMalloc) */
+            const size_t roof = (kind_ == DevicePool && need >= ((size_t)64 << 20)) ? std::max(need + need / 2 + (1u << 20), (size_t)13 << 30)
                                 : (kind_ == PinnedHost && need >= ((size_t)2 << 20)) ? std::max(need + need / 2 + (1u << 20), (size_t)32 << 20) : need + need / 2 + (1u << 20);
             if (e.device != t_device || e.bytes < need || e.bytes > roof) continue;
             if (best == parked_.size() || e.bytes < parked_[best].bytes) best = i;
@@ -355,11 +402,22 @@ struct PoolRecord {
     size_t bytes = 0, chunkBytes = 0;
     std::vector<float> candidatesMs; /* hipMemset time of every candidate allocation (empty: never timed) */
     std::vector<float> fillMs;       /* time of one fill of the batch on every candidate (empty: never shopped) */
-    std::vector<std::string> kinds;  /* how every candidate was built: "vmm256", "vmm1024", "malloc" ... (empty: never shopped) */
+    std::vector<std::string> kinds;  /* how every candidate was built: "vmm256", "malloc" ... (empty: never shopped) */
+    std::vector<std::string> ranges; /* "address+bytes" of every candidate (a GPU fault address can be placed against them) */
     int kept = 0;
 };
 static std::mutex g_poolRecMu;
 static std::map<void *, PoolRecord> g_poolRecords;
+namespace { void forget_pool_record(void *pool) { std::lock_guard<std::mutex> lk(g_poolRecMu); g_poolRecords.erase(pool); } }
+/* the record of a pool nobody has timed yet: how it was built (looked up by address: the pool may have been built by another thread) */
+static PoolRecord fresh_pool_record(void *pool, size_t bytes) {
+    PoolRecord rec;
+    const size_t chunk = pool_chunk_bytes(pool);
+    rec.mode = chunk ? "vmm" : "malloc";
+    rec.chunkBytes = chunk;
+    rec.bytes = bytes;
+    return rec;
+}
 
 struct dpx_batch {
     int device = -1; /* the device the batch lives on */
@@ -527,6 +585,7 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
  * lesson: size the buffers once, outside the loop -- cuda/LNW/LinearNeedlemanWunschV9.cu:26-46, V14.cu:144-213). */
 int dpx_pool_reserve(size_t bytes, int count) {
     if (count < 1 || count > 2 || bytes == 0) return DPX_ERR_INVALID;
+    if (bytes >= ((size_t)16 << 30)) count = 1; /* (only one pool of 16 GiB or more stays parked per device: a second one would be built and dropped at once) */
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
     void *p[2] = {nullptr, nullptr};
@@ -536,7 +595,13 @@ int dpx_pool_reserve(size_t bytes, int count) {
         hipError_t e = g_matCache.take(&p[k], bytes, &got[k], &fresh);
         if (e != hipSuccess) { for (int j = 0; j < k; j++) g_matCache.park(p[j], got[j]); return hip_fail(e, "dpx_pool_reserve"); }
     }
-    for (int k = 0; k < count; k++) g_matCache.park(p[k], got[k]);
+    for (int k = 0; k < count; k++) {
+        { /* the pool's record, for the batch (of whatever thread) that takes it */
+            std::lock_guard<std::mutex> lk(g_poolRecMu);
+            if (!g_poolRecords.count(p[k])) g_poolRecords[p[k]] = fresh_pool_record(p[k], got[k]);
+        }
+        g_matCache.park(p[k], got[k]);
+    }
     /* ... and the streams of the batches that will take the pools: a batch runs on its own stream plus a side stream for the pairs its
      * main kernel leaves over (an odd pair beside the couples of the packed kernel), and creating a stream costs ~10 ms each time the
      * cache is empty (DPX_TRACE of the batched driver: "create: stream 9.6 ms" twice for two batches in flight) */
@@ -743,10 +808,15 @@ static uint32_t fill_waves_per_block(size_t waves) {
 /* DPX_TUNE_PLACEMENT (callers that fill a resident batch many times: bench.py, iterative drivers).  The same fill runs up to
  * 27 % apart on two pools of the same construction (ANW 1000 x 1024^2: 1.05 vs 1.20 ms, alternating from one allocation to the
  * next while hipMemset sees no difference; LSW 10k x 1024^2: +-2 %; tools/mode_watch.py, profiles/r03/): the mode belongs to the
- * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: five
- * candidate pools of different constructions (see below), one warm-up + three timed fills each, the fastest is kept (and parked for
- * later batches), the losers are freed together when the last candidate has been timed.  Every candidate's
- * construction and times go into the pool record (dpx_batch_describe -> bench.py roofline.pool). */
+ * allocation -- where its physical chunks lie -- and only the fill itself shows it.  So the batch shops with its own fill: up to five
+ * candidate pools of the SAME construction, one warm-up + three timed fills each, the fastest is kept (and parked for later batches),
+ * the losers are freed together when the last candidate has been timed.  Every candidate's address range and times go into the pool
+ * record (dpx_batch_describe -> bench.py roofline.pool; fillMs[0] is the pool a caller without the flag would have got).
+ * Round 3 also compared CONSTRUCTIONS here (candidates of 512-MiB, 1-GiB and 2-GiB chunks): twice in ~60 runs a process died with a GPU
+ * memory access fault while such a candidate was being filled (profiles/r03/gpu_fault_while_shopping.txt), never in hundreds of runs on
+ * 256-MiB chunks.  Those ranges were reserved with alignment 0 and their chunks mapped at offsets that were multiples of 2 MiB only, not
+ * of the chunk size or of the queried granularity (pool_alloc now reserves with the chunk size as alignment); whether that was the
+ * cause cannot be shown from one clean run, so the branch is gone (round 4) rather than shipped on trust. */
 static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -763,48 +833,33 @@ static void shop_pool_by_fill(dpx_batch *b, PoolRecord &rec, PhaseTrace &trace) 
         if (e != hipSuccess) { (void)hipGetLastError(); return -1.f; }
         return ms / 3.f;
     };
+    auto kind_of = [](void *pool) { const size_t c = pool_chunk_bytes(pool); return c ? "vmm" + std::to_string(c >> 20) : std::string("malloc"); };
+    auto range_of = [&](void *pool) { char t[64]; snprintf(t, sizeof t, "%p+%zu", pool, b->matPoolBytes); return std::string(t); };
     const size_t bytes = b->matPoolBytes;
     void *best = b->dMat;
     float bestMs = time_fill();
     rec.fillMs.assign(1, bestMs);
     rec.kept = 0;
-    auto kind_of = [](const char *mode, size_t chunkBytes) { return !strcmp(mode, "vmm") ? "vmm" + std::to_string(chunkBytes >> 20) : std::string(mode); };
-    rec.kinds.assign(1, kind_of(rec.mode.c_str(), rec.chunkBytes));
-    /* The candidates differ in CONSTRUCTION (round 3, tools/group_sweep.sh on a slow box of the pool: the headline fill takes 3.82 ms on
-     * 256-MiB chunks, 3.58 on one hipMalloc, 3.37 on 1-GiB chunks -- on the fast boxes 256-MiB chunks win, 3.2 against 3.3-3.6):
-     * 1-GiB, 2-GiB and 512-MiB chunks, then the first construction once more (one hipMalloc, like one chunk for the whole pool, never
-     * won: 3.58-3.7 ms everywhere).  With DPX_POOL / DPX_POOL_CHUNK_MB set every candidate is built the way they say (up to three
-     * more of them, as before). */
-    /* ... but comparing constructions is OPT-IN (DPX_POOL_SHOP_KINDS=1): twice in ~60 runs a process died with a GPU memory access fault
-     * while a candidate built from 512-MiB / 1-GiB / 2-GiB chunks was being filled (profiles/r03/gpu_fault_while_shopping.txt), never
-     * in hundreds of runs on 256-MiB chunks.  Without the knob every candidate is built like the first one. */
-    const bool kindsOn = [] { const char *e = getenv("DPX_POOL_SHOP_KINDS"); return e && atoi(e) != 0; }();
-    const bool forced = getenv("DPX_POOL") || getenv("DPX_POOL_CHUNK_MB") || !kindsOn;
-    const long long builds[4] = {forced ? 0 : (long long)1 << 30, forced ? 0 : (long long)2 << 30, forced ? 0 : (long long)512 << 20, 0};
+    rec.kinds.assign(1, kind_of(best));
+    rec.ranges.assign(1, range_of(best));
     /* NO pool is unmapped before the last candidate has been filled: the losers are freed together at the end (memory permitting -- the
-     * loop stops when the next candidate would not leave 8 GiB free).  One run of this loop that freed every loser at once (so that the
-     * next candidate could be mapped at the address range just given back) ended in a GPU memory access fault during a candidate's four
-     * fills under rocprofv3 (profiles/r03/gpu_fault_while_shopping.txt; one in ~40 runs, never seen with one construction). */
+     * loop stops when the next candidate would not leave 8 GiB of THIS device's memory free; every rank of a multi-GPU job shops on its
+     * own device only).  Five candidates in all, no early stop: a rehearsal that stopped after [3.73, 3.59] -- "both modes seen" -- ran
+     * at 2907 GCUPS, the next one found 3.40 with its fourth candidate after [3.82, 3.80, 3.76]. */
     std::vector<void *> losers;
-    float lo = bestMs, hi = bestMs;
-    /* (five candidates in all, no early stop: a rehearsal that stopped after [3.73, 3.59] -- "both modes seen" -- ran at 2907 GCUPS, the next
-     * one found 3.40 with its fourth candidate after [3.82, 3.80, 3.76]) */
     for (int k = 1; k < 5 && bestMs > 0.f; k++) {
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < bytes + ((size_t)8 << 30)) { (void)hipGetLastError(); break; }
         void *cand = nullptr;
-        t_poolBuild = builds[k - 1];
-        const hipError_t ae = pool_alloc(&cand, bytes);
-        t_poolBuild = 0;
-        if (ae != hipSuccess) { (void)hipGetLastError(); break; }
-        const PoolStats built = t_poolStats;
+        if (pool_alloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        rec.kinds.push_back(kind_of(cand));
+        rec.ranges.push_back(range_of(cand));
+        if (trace.on) { fprintf(stderr, "[dpx] pool candidate %d: %s %s\n", k, rec.kinds.back().c_str(), rec.ranges.back().c_str()); fflush(stderr); }
         set_pool(cand);
         const float ms = time_fill();
         rec.fillMs.push_back(ms);
-        rec.kinds.push_back(kind_of(built.mode, built.chunkBytes));
         rec.candidatesMs.push_back(time_memset(cand, bytes, b->stream));
-        if (ms > 0.f) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
-        if (ms > 0.f && ms < bestMs) { losers.push_back(best); best = cand; bestMs = ms; rec.kept = k; rec.mode = built.mode; rec.chunkBytes = built.chunkBytes; }
+        if (ms > 0.f && ms < bestMs) { losers.push_back(best); best = cand; bestMs = ms; rec.kept = k; rec.mode = pool_chunk_bytes(cand) ? "vmm" : "malloc"; rec.chunkBytes = pool_chunk_bytes(cand); }
         else losers.push_back(cand);
     }
     set_pool(best);
@@ -1424,11 +1479,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
             auto it = g_poolRecords.find(pool);
             if (it != g_poolRecords.end()) { rec = it->second; known = true; }
         }
-        if (!known) {
-            rec.mode = t_poolStats.mode;
-            rec.chunkBytes = t_poolStats.chunkBytes;
-            rec.bytes = b->matPoolBytes;
-        }
+        if (!known) rec = fresh_pool_record(pool, b->matPoolBytes);
         b->tunePool = tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30) && !b->guardBytes; /* (the memset probe would wipe the band) */
         b->tuneShop = b->tunePool && fresh && probeEnv != 1; /* DPX_POOL_PROBE=1: time only, no shopping */
         if (b->tunePool) rec.candidatesMs.assign(1, time_memset(pool, b->matPoolBytes, b->stream));
@@ -1939,6 +1990,10 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
         if (!r.kinds.empty() && (size_t)len < cap) {
             len += snprintf(buf + len, cap - (size_t)len, " pool_kinds=");
             for (size_t k = 0; k < r.kinds.size() && (size_t)len < cap; k++) len += snprintf(buf + len, cap - (size_t)len, "%s%s", k ? "," : "", r.kinds[k].c_str());
+        }
+        if (!r.ranges.empty() && (size_t)len < cap) {
+            len += snprintf(buf + len, cap - (size_t)len, " pool_ranges=");
+            for (size_t k = 0; k < r.ranges.size() && (size_t)len < cap; k++) len += snprintf(buf + len, cap - (size_t)len, "%s%s", k ? "," : "", r.ranges[k].c_str());
         }
     }
     return DPX_OK;

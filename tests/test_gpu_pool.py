@@ -54,10 +54,13 @@ def test_tuned_placement_records_every_candidate(gpu):
     sets = [float(x) for x in str(d["pool_memset_ms"]).split(",")]
     assert 1 <= len(fills) <= 5 and len(sets) == len(fills) and 0 <= d["pool_kept"] < len(fills)
     assert all(0.05 < f < 50 for f in fills) and fills[d["pool_kept"]] == min(fills)
-    # every candidate is built like the first one (256-MiB chunks); other constructions are opt-in (DPX_POOL_SHOP_KINDS=1: two GPU
-    # memory access faults in ~60 runs while candidates of 512-MiB / 1-GiB / 2-GiB chunks were being filled -- never exercised here)
+    # every candidate is built like the first one (256-MiB chunks; round 3's comparison of constructions is gone: two GPU memory access
+    # faults in ~60 runs while candidates of 512-MiB / 1-GiB / 2-GiB chunks were being filled), and its address range is on record
     kinds = str(d["pool_kinds"]).split(",")
     assert kinds == ["vmm256"] * len(fills) and (d["pool"], d["pool_chunk_mb"]) == ("vmm", 256)
+    ranges = [r.split("+") for r in str(d["pool_ranges"]).split(",")]
+    assert len(ranges) == len(fills) and all(int(a, 16) % (256 << 20) == 0 and int(n) == d["pool_bytes"] for a, n in ranges)  # reserved with the chunk size as alignment
+    assert len({a for a, _ in ranges}) == len(ranges)
     d2, res2, _ = _fill(gpu, sb, flags=gpu.TUNE_PLACEMENT)       # the parked pool comes back with its record, nothing is re-timed
     assert d2["pool_fill_ms"] == d["pool_fill_ms"] and d2["pool_memset_ms"] == d["pool_memset_ms"]
     assert all(np.array_equal(x, y) for x, y in zip(res, res2))
