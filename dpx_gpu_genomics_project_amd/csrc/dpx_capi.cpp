@@ -111,14 +111,15 @@ size_t vmm_granularity(int device) {
     return g;
 }
 
-/* Tearing a range down.  ROCm 7.2 crashed inside hipMemAddressFree (SIGSEGV in libamdhip64, profiles/r03/vmm_address_free_crash.txt) when
- * a range was dropped with ONE hipMemUnmap over all of it: the runtime keeps one mapping object per hipMemMap call, an unmap that does
- * not match one of them leaves the other mappings (and their physical chunks) alive, and hipMemAddressFree then walks a range that still
- * holds live mappings.  So the load-bearing step is the per-chunk unmap: every mapping is undone with exactly the (address, size) it was
- * made with, then its handle is released, and only then is the address range given back.  The device is idle before the first unmap
- * (no kernel may still write the range); the second wait of rounds 3 (between release and address free) was belt and braces and is
- * gone.  Every status is checked: on a failure the range stays in g_vmmRanges (nothing is double-freed, the leak is visible) and the
- * error is left in dpx_last_error(). */
+/* Tearing a range down.  ROCm 7.2 crashed inside hipMemAddressFree (SIGSEGV in libamdhip64, profiles/r03/vmm_address_free_crash.txt) in
+ * about half the runs of the pool tests.  The crashing version (commit 46f7574) already undid every mapping with exactly the (address,
+ * size) it was made with, released the handles and then freed the address range -- in this order; what the fix (c07d102) added, and
+ * what the crash therefore depended on, are the two waits for the device: one before the first unmap (work of ANY stream of this
+ * process, e.g. a hipMemsetAsync of the previous candidate or a fill on a side stream, may still touch the range) and one between the
+ * releases and hipMemAddressFree (unmap / release are queued inside the runtime).  The two were added together and never separated;
+ * both stay.  One hipMemUnmap over the whole range instead of one per chunk is a different bug: the chunks behind the first stayed
+ * allocated (tools/pool_leak.py).  Every status is checked: on a failure the range stays in g_vmmRanges (nothing is freed twice, the
+ * leak is visible) and the error is left in dpx_last_error(). */
 bool vmm_release(void *va, VmmRange &r, size_t mappedBytes) {
     static const bool dbg = getenv("DPX_TRACE_VMM") != nullptr;
     if (dbg) { fprintf(stderr, "[vmm] release [%p, %p) mapped %zu chunks %zu\n", va, (void *)((char *)va + r.bytes), mappedBytes, r.chunks.size()); fflush(stderr); }
@@ -137,6 +138,7 @@ bool vmm_release(void *va, VmmRange &r, size_t mappedBytes) {
         bad = hipMemRelease(c.first);
         where = "hipMemRelease";
     }
+    if (bad == hipSuccess) { bad = hipDeviceSynchronize(); where = "hipDeviceSynchronize"; }
     if (bad == hipSuccess) { bad = hipMemAddressFree(r.reserved, r.reservedBytes); where = "hipMemAddressFree"; }
     if (bad != hipSuccess) {
         t_err = std::string("matrix pool teardown: ") + where + ": " + hipGetErrorString(bad);
