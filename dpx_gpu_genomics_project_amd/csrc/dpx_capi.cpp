@@ -307,13 +307,14 @@ void BufCache::park(void *ptr, size_t bytes) {
         if (t_device < 0 || bytes > maxBytes_) {
             evicted.push_back(ptr);
         } else {
-            /* per device: at most one parked buffer of 16 GiB or more, at most two of a GiB or more (two batches in flight on
-             * two pools of a few GiB each is the shape of a pipelined driver; tens of GB twice over is not worth holding) */
+            /* per device: at most one parked buffer of 16 GiB or more, at most eight of a GiB or more and 48 GiB of them (a pipelined driver
+             * keeps up to eight batches in flight on pools of a few GiB each -- dpx_main -inflight; tens of GB twice over is not worth holding) */
             const size_t big = (size_t)1 << 30, huge = (size_t)16 << 30;
-            size_t bigOnes = 0;
+            size_t bigOnes = 0, bigBytes = bytes;
             for (size_t i = parked_.size(); i-- > 0;) { /* newest first: the oldest go */
                 if (parked_[i].device != t_device || parked_[i].bytes < big || bytes < big) continue;
-                const bool drop = bytes >= huge || parked_[i].bytes >= huge || ++bigOnes >= 2;
+                bigBytes += parked_[i].bytes;
+                const bool drop = bytes >= huge || parked_[i].bytes >= huge || ++bigOnes >= 8 || bigBytes > ((size_t)48 << 30);
                 if (drop) { evicted.push_back(parked_[i].ptr); total_ -= parked_[i].bytes; parked_.erase(parked_.begin() + (long)i); }
             }
             while (!parked_.empty() && (parked_.size() >= maxEntries_ || total_ + bytes > maxBytes_)) {
@@ -351,7 +352,10 @@ struct StreamCache {
 hipError_t stream_take(hipStream_t *out) {
     {
         std::lock_guard<std::mutex> lk(g_streams.mu);
-        for (size_t i = 0; i < g_streams.parked.size(); i++)
+        /* the most recently parked one first: a pipeline of two batches in flight then keeps using the same two streams.  The runtime
+         * maps streams onto four hardware queues; cycling through six parked streams put the fill of batch k+1 on the queue of batch
+         * k's traceback every few batches, where it waited for it (profiles/r04/e2e_long_timeline_*.txt) */
+        for (size_t i = g_streams.parked.size(); i-- > 0;)
             if (g_streams.parked[i].second == t_device) {
                 *out = g_streams.parked[i].first;
                 g_streams.parked.erase(g_streams.parked.begin() + (long)i);
@@ -586,12 +590,12 @@ int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBy
  * on a helper thread while it is still parsing its input: building a pool costs tens of ms per GiB (the reference's V9 / V14
  * lesson: size the buffers once, outside the loop -- cuda/LNW/LinearNeedlemanWunschV9.cu:26-46, V14.cu:144-213). */
 int dpx_pool_reserve(size_t bytes, int count) {
-    if (count < 1 || count > 2 || bytes == 0) return DPX_ERR_INVALID;
+    if (count < 1 || count > 8 || bytes == 0) return DPX_ERR_INVALID;
     if (bytes >= ((size_t)16 << 30)) count = 1; /* (only one pool of 16 GiB or more stays parked per device: a second one would be built and dropped at once) */
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
-    void *p[2] = {nullptr, nullptr};
-    size_t got[2] = {0, 0};
+    void *p[8] = {nullptr};
+    size_t got[8] = {0};
     for (int k = 0; k < count; k++) {
         bool fresh = false;
         hipError_t e = g_matCache.take(&p[k], bytes, &got[k], &fresh);
@@ -608,9 +612,9 @@ int dpx_pool_reserve(size_t bytes, int count) {
      * main kernel leaves over (an odd pair beside the couples of the packed kernel), and creating a stream costs ~10 ms each time the
      * cache is empty (DPX_TRACE of the batched driver: "create: stream 9.6 ms" twice for two batches in flight) */
     {
-        hipStream_t extra[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t extra[10] = {nullptr};
         int made = 0;
-        for (int k = 0; k < 2 * count; k++)
+        for (int k = 0; k < count + 2; k++) /* (one per batch in flight + two for side kernels) */
             if (hipStreamCreateWithFlags(&extra[made], hipStreamNonBlocking) == hipSuccess) made++;
             else (void)hipGetLastError();
         for (int k = 0; k < made; k++) stream_park(extra[k]);
@@ -621,11 +625,11 @@ int dpx_pool_reserve(size_t bytes, int count) {
 /* The same for the pinned host buffers that the result text of a batch is copied into (dpx_batch_output_end / _take): pinning
  * 8 MB costs 1-2 ms, and a pipelined driver holds up to three of them (one being printed, two batches in flight). */
 int dpx_text_reserve(size_t bytes, int count) {
-    if (count < 1 || count > 4 || bytes == 0 || bytes > ((size_t)1 << 30)) return DPX_ERR_INVALID;
+    if (count < 1 || count > 9 || bytes == 0 || bytes > ((size_t)1 << 30)) return DPX_ERR_INVALID;
     int rc = bind_device();
     if (rc != DPX_OK) return rc;
-    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t got[4] = {0, 0, 0, 0};
+    void *p[9] = {nullptr};
+    size_t got[9] = {0};
     for (int k = 0; k < count; k++) {
         hipError_t e = g_tbHostCache.take(&p[k], bytes, &got[k]);
         if (e != hipSuccess) { for (int j = 0; j < k; j++) g_tbHostCache.park(p[j], got[j]); return hip_fail(e, "dpx_text_reserve"); }

@@ -2862,20 +2862,28 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
 /* -----------------------------------------------------------------------------------------------------
  * Wave-cooperative traceback (LSW / LNW / ANW, every matrix layout of the fill kernels).
  * The lane-per-pair walk above pays one dependent HBM round trip per path step (1100 of them on a 1024 x 1024 pair).  Here
- * one WAVE owns a pair: its 64 lanes fetch a window of the matrix around the walker in one go -- 4 row groups (32 rows) x 64
- * columns of every plane, the 8 rows of a group and column with one 16-byte load (layouts with fewer than 8 rows per lane: 8- or
- * 4-byte pieces), plus the query / reference characters of those rows / columns -- into LDS, and the walk then runs out of LDS
- * until it leaves the window through its top or its left edge: one HBM round trip per ~32 steps of a diagonal path instead of
- * one per step.
- * Round 3: the walk is SCALAR.  The window is a row-major int16 image per plane (a row is 128 bytes) in which the borders (row
- * 0, column 0) are ordinary cells, so the neighbours of a step are ds_read_i16 off ONE address, issued together with the two
- * character reads (one LDS round trip per step, round 2: two to three); everything they return goes through
- * v_readfirstlane, so position, score, state, the emitted characters and every branch live on the scalar unit (round 2: ~100
- * vector instructions per step in all 64 lanes).  Lane 0 stores four characters per line every fourth step.
- * LDS: planes x 4 KiB + the characters (dynamic).
+ * one WAVE owns a pair: lane c fetches column cLo + c of a window of the matrix around the walker -- 64 rows (ANW: 32 rows of
+ * every plane) x 64 columns, the 8 rows of a row group with one 16-byte load (layouts with fewer than 8 rows per lane: 8- or
+ * 4-byte pieces) -- into LDS (one 144-byte line per column and plane, borders included as ordinary cells), and the walk runs
+ * until it leaves the window through its top or its left edge: one HBM round trip per ~64 steps of a diagonal path.
+ * Round 4: the walk takes RUNS, not steps.  Round 3 walked on the scalar unit, one cell per trip: an LDS round trip for three
+ * scores and two characters, five v_readfirstlane and the branches on them -- about 340 issue cycles per path step, and the
+ * traceback of a batch cost as much as its fill (10 000 pairs of 1024 x 1024: 4.4 ms against 3.2 ms).  Which way the path leaves a
+ * cell depends on that cell's neighbourhood only, so the 64 lanes each decide ONE cell of the line the path would follow next --
+ * lane l the cell of the walker's diagonal in column l; in ANW's gap states the cells of the walker's row (INSERTION) or column
+ * (DELETION) -- from four LDS reads at their own address, and a ballot gives the number of steps the path really follows that
+ * line: the length of the run of "diagonal" decisions below the walker's lane (LSW: up / left / diagonal / stop at H = 0; LNW:
+ * INSERTION over DELETION over diagonal, borders included; ANW: the SCORING state's choice, "the gap was opened here" for the two
+ * gap states, c++/backtrack.cpp:214-356).  The lanes of the run store their own three characters.  Alignments worth computing
+ * are mostly long diagonal runs: a 1024 x 1024 pair of the benchmark is ~90 trips instead of ~2050.
  * ----------------------------------------------------------------------------------------------------- */
-constexpr int kWinGroups = 4, kWinCols = 64, kWinRows = 8 * kWinGroups, kWinPlane = kWinRows * kWinCols;
-size_t dpx_traceback_wave_lds(int planes) { return (size_t)planes * kWinPlane * sizeof(int16_t) + kWinRows + 8 + kWinCols + 8; }
+template <int PLANES> struct TbWin {
+    static constexpr int G = PLANES == 3 ? 4 : 8;      /* row groups of a window */
+    static constexpr int WR = 8 * G;                   /* rows R0+1 .. R0+WR; columns cLo .. cLo+63, one per lane */
+    static constexpr int CS = WR + 8;                  /* int16 elements between two columns in LDS: 16-byte aligned lines, banks spread */
+    static constexpr int kBytes = PLANES * 64 * CS * 2;
+};
+size_t dpx_traceback_wave_lds(int planes) { return planes == 3 ? (size_t)TbWin<3>::kBytes : (size_t)TbWin<1>::kBytes; }
 
 /* the 8 rows 8*grp+1 .. 8*grp+8 of column jc (>= 1) of `plane`, whatever the layout: one 16-byte piece where a lane owns >= 8 rows
  * (wavefront-tiled with 8-row sub-tiles, tile layout), otherwise the pieces of 8 / Rr neighbouring lanes (they sit in different chunks) */
@@ -2899,9 +2907,10 @@ __device__ __forceinline__ u32x4 tb_load_group8(const int16_t *base, const dpx_p
 template <int PLANES>
 __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int algo, int R, const int32_t *endRow,
                                                        const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
+    using W = TbWin<PLANES>;
+    constexpr int G = W::G, WR = W::WR, CS = W::CS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemTb[];
-    int16_t *win = reinterpret_cast<int16_t *>(smemTb); /* win[plane * kWinPlane + (ii - R0 - 1) * 64 + (jj - cLo)] = plane[ii][jj] */
-    unsigned char *wq = smemTb + PLANES * kWinPlane * sizeof(int16_t), *wr = wq + kWinRows + 8;
+    int16_t *win = reinterpret_cast<int16_t *>(smemTb); /* win[(plane * 64 + (jj - cLo)) * CS + (ii - R0 - 1)] = plane[ii][jj] */
     const int p = blockIdx.x;
     const int lane = threadIdx.x;
     if (p >= numPairs) return;
@@ -2916,47 +2925,54 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     const int cap = (m + n + 1 + 3) & ~3;
     char *lr = tb + tbOff[p], *lx = lr + cap, *lq = lx + cap;
     int pos = cap;
-    uint32_t accR = 0, accX = 0, accQ = 0;
     const int match = a.match, mismatch = a.mismatch, g = a.gapOpen, ext = a.gapExtend;
     /* H on row 0 / column 0, `len` cells from the corner (TbView::get): LNW len * gap, ANW open + len * extend (0 in the corner), LSW 0 */
     auto bval = [&](const int len) -> int { return algo == DPX_K_LNW ? len * g : (algo == DPX_K_ANW ? (len ? g + len * ext : 0) : 0); };
-#define EMITW(rc_, xc_, qc_)                                                                     \
-    {                                                                                            \
-        --pos;                                                                                   \
-        accR = (accR << 8) | (uint32_t)(unsigned char)(rc_);                                     \
-        accX = (accX << 8) | (uint32_t)(unsigned char)(xc_);                                     \
-        accQ = (accQ << 8) | (uint32_t)(unsigned char)(qc_);                                     \
-        if ((pos & 3) == 0 && lane == 0) {                                                       \
-            *reinterpret_cast<uint32_t *>(lr + pos) = accR;                                      \
-            *reinterpret_cast<uint32_t *>(lx + pos) = accX;                                      \
-            *reinterpret_cast<uint32_t *>(lq + pos) = accQ;                                      \
-        }                                                                                        \
-    }
+    /* where the 16-byte piece (8 rows of a row group, one column) lies: shifts only for the two layouts whose lanes own >= 8 rows */
+    const int Q = Rr >> 3, lgQ = Q == 2 ? 1 : 0;
+    const int kind = Rr >= 8 ? (pr.lanes == 64 ? 0 : pr.lanes == 16 ? 1 : 2) : 2;
+    const uint32_t cs = pr.chunkStride; /* (tile layout: the pair's first lane) */
+    auto piece = [&](const int pl, const int grp, const int jc) -> u32x4 {
+        if (kind == 0) { /* wavefront-tiled (dpx_tiled_index + dpx_tile_off) */
+            const int l = (grp >> lgQ) & 63, kk = grp >> (lgQ + 6), sub = grp & (Q - 1);
+            const size_t T = (size_t)kk * (size_t)n + (size_t)(jc - 1) + (size_t)l;
+            return *reinterpret_cast<const u32x4 *>(base + T * cs + (size_t)(((((pl << lgQ) + sub) << 6) + l) << 3));
+        }
+        if (kind == 1) { /* tile layout of the lane-packed kernels (dpx_wtile_index) */
+            const int l = grp >> lgQ, h = grp & (Q - 1), lam = (int)cs + l, skew = l + ((int)cs & 7), j0 = jc - 1;
+            const size_t t = (size_t)(((j0 >> 3) + 1) * 8 + skew - 1);
+            return *reinterpret_cast<const u32x4 *>(base + t * (size_t)(PLANES * Q * 512) + (size_t)((((pl << lgQ) + h) << 9) + ((lam >> 3) << 6) + ((j0 & 7) << 3)));
+        }
+        return tb_load_group8(base, pr, Rr, PLANES, pl, grp, jc, n);
+    };
     int i = __builtin_amdgcn_readfirstlane(endRow[p]), j = __builtin_amdgcn_readfirstlane(endCol[p]);
-    int R0 = 1 << 28, cLo = 1 << 28; /* window: rows R0+1 .. R0+32 (R0 = 8 * first row group; may be negative), columns cLo .. cLo+63 */
-    auto load_window = [&](const int ii, const int jj) __attribute__((always_inline)) { /* (ii, jj) in its bottom-right corner region */
-        const int gBase = ((ii - 1) >> 3) - (kWinGroups - 1);
+    int R0 = 1 << 28, cLo = 1 << 28;
+    uint32_t chR = 0u, chQ = 0u; /* reference character of this lane's column; query character of window row `lane` */
+    /* window with (ii, jj) in its bottom-right corner region */
+    auto load_window = [&](const int ii, const int jj) {
+        const int gBase = ((ii - 1) >> 3) - (G - 1);
         R0 = gBase * 8;
-        cLo = jj - (kWinCols - 1);
+        cLo = jj - 63;
         const int jc = cLo + lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the previous window's reads are done before it is overwritten */
         __builtin_amdgcn_wave_barrier();
-        u32x4 v[PLANES][kWinGroups];
+        u32x4 v[PLANES][G];
 #pragma unroll
         for (int pl = 0; pl < PLANES; pl++) {
 #pragma unroll
-            for (int gi = 0; gi < kWinGroups; gi++) { /* the loads first, all in flight together */
+            for (int gi = 0; gi < G; gi++) { /* all loads in flight together */
                 const int grp = gBase + gi;
                 v[pl][gi] = u32x4{0u, 0u, 0u, 0u};
-                if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = tb_load_group8(base, pr, Rr, PLANES, pl, grp, jc, n);
+                if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = piece(pl, grp, jc);
             }
         }
+        { const int qi = R0 + lane; chQ = (lane < WR && qi >= 0 && qi < m) ? qry[qi] : 0u; } /* query character of row R0 + 1 + lane */
+        chR = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0u;
+        if (algo != DPX_K_LSW) { /* the borders of H as cells: column 0 and row 0 (LSW: zeros, as loaded) */
 #pragma unroll
-        for (int pl = 0; pl < PLANES; pl++) {
-#pragma unroll
-            for (int gi = 0; gi < kWinGroups; gi++) {
+            for (int gi = 0; gi < G; gi++) {
                 const int grp = gBase + gi;
-                if (pl == 0 && algo != DPX_K_LSW && (jc == 0 || grp < 0)) { /* the borders of H as cells: column 0 and row 0 (other cells here are never read) */
+                if (jc == 0 || grp < 0) {
                     uint32_t d[4];
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -2965,93 +2981,128 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
                         const int v1 = jc == 0 ? (r1 >= 0 ? bval(r1) : 0) : (r1 == 0 && jc > 0 ? bval(jc) : 0);
                         d[e >> 1] = ((uint32_t)(uint16_t)v1 << 16) | (uint32_t)(uint16_t)v0;
                     }
-                    v[pl][gi] = u32x4{d[0], d[1], d[2], d[3]};
+                    v[0][gi] = u32x4{d[0], d[1], d[2], d[3]};
                 }
-                int16_t *dst = win + pl * kWinPlane + (gi * 8) * kWinCols + lane;
-                const uint32_t w4[4] = {v[pl][gi].x, v[pl][gi].y, v[pl][gi].z, v[pl][gi].w};
-#pragma unroll
-                for (int e = 0; e < 8; e++) dst[e * kWinCols] = (int16_t)(w4[e >> 1] >> (16 * (e & 1)));
             }
         }
-        if (lane < kWinRows) { const int qi = R0 + lane; wq[lane] = (qi >= 0 && qi < m) ? qry[qi] : 0; } /* wq[ii - R0 - 1] = query character of row ii */
-        wr[lane] = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0;                                               /* wr[jj - cLo] = reference character of column jj */
+#pragma unroll
+        for (int pl = 0; pl < PLANES; pl++)
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) *reinterpret_cast<u32x4 *>(win + (pl * 64 + lane) * CS + gi * 8) = v[pl][gi];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     /* rows i-1, i and columns j-1, j must lie inside the window (borders are cells of it) */
-    auto need_window = [&]() -> bool { return i - 1 <= R0 || i > R0 + kWinRows || j - 1 < cLo || j > cLo + kWinCols - 1; };
-    auto rfl = [](const int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
-    if (algo == DPX_K_LSW) {
-        int h = 0;
-        if (i > 0 && j > 0) { load_window(i, j); h = rfl(win[(i - R0 - 1) * kWinCols + (j - cLo)]); }
-        while (h > 0) {
-            if (need_window()) load_window(i, j);
-            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
-            const int vu = c[-kWinCols], vl = c[-1], vd = c[-kWinCols - 1], vq = wq[i - R0 - 1], vr = wr[j - cLo]; /* one LDS round trip */
-            const int up = rfl(vu), left = rfl(vl), dg = rfl(vd), qc = rfl(vq), rc = rfl(vr);
-            if (up + g == h) { EMITW('_', ' ', qc); i--; h = up; }
-            else if (left + g == h) { EMITW(rc, ' ', '_'); j--; h = left; }
-            else { EMITW(rc, qc == rc ? '*' : '|', qc); i--; j--; h = dg; }
-        }
-    } else if (algo == DPX_K_LNW) {
-        while (i != 0 || j != 0) {
-            if (need_window()) load_window(max(i, 1), max(j, 1)); /* (a window anchored on row 1 / column 1 also serves row 0 / column 0) */
-            if (i == 0) { const int rc = rfl((int)wr[j - cLo]); EMITW(rc, ' ', '_'); j--; continue; }     /* row-0 border: QUERY_INSERTION */
-            if (j == 0) { const int qc = rfl((int)wq[i - R0 - 1]); EMITW('_', ' ', qc); i--; continue; }  /* column-0 border: QUERY_DELETION */
-            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
-            const int vu = c[-kWinCols], vl = c[-1], vd = c[-kWinCols - 1], vq = wq[i - R0 - 1], vr = wr[j - cLo];
-            const int up = rfl(vu), left = rfl(vl), dg = rfl(vd), qc = rfl(vq), rc = rfl(vr);
-            const bool eq = qc == rc;
-            const int mm = dg + (eq ? match : mismatch);
-            const int del = up + g, ins = left + g;
-            const int vmax = max(del, mm);
-            if (ins >= vmax) { EMITW(rc, ' ', '_'); j--; }
-            else if (del >= mm) { EMITW('_', ' ', qc); i--; }
-            else { EMITW(rc, eq ? '*' : '|', qc); i--; j--; }
-        }
-    } else if constexpr (PLANES == 3) { /* ANW: the three-state walk of tb_walk_lane (c++/backtrack.cpp:214-356) */
-        int cur = 0; /* 0 SCORING, 1 INSERTION, 2 DELETION */
-        while (i != 0 && j != 0) {
-            if (need_window()) load_window(i, j);
-            const int16_t *c = win + (i - R0 - 1) * kWinCols + (j - cLo);
-            if (cur == 0) {
-                const int vd = c[-kWinCols - 1], vI = c[kWinPlane], vD = c[2 * kWinPlane], vq = wq[i - R0 - 1], vr = wr[j - cLo];
-                const int dg = rfl(vd), I = rfl(vI), D = rfl(vD), qc = rfl(vq), rc = rfl(vr);
-                const bool eq = qc == rc;
-                const int mm = dg + (eq ? match : mismatch);
-                const int vmax = max(D, mm);
-                if (I >= vmax) cur = 1;
-                else if (D >= mm) cur = 2;
-                else { EMITW(rc, eq ? '*' : '|', qc); i--; j--; }
-            } else if (cur == 1) {
-                const int vh = c[-1], vi = c[kWinPlane - 1], vr = wr[j - cLo];
-                const int hl = rfl(vh), il = rfl(vi), rc = rfl(vr);
-                if (j == 1 || hl + g + ext >= il + ext) cur = 0;
-                EMITW(rc, ' ', '_'); j--;
+    auto need_window = [&]() -> bool { return i - 1 <= R0 || i > R0 + WR || j - 1 < cLo || j > cLo + 63; };
+    auto cell = [&](const int pl, const int col, const int row) -> int { return (int)win[(pl * 64 + col) * CS + row]; };
+    /* number of lanes that continue a run which starts at lane `from` and goes DOWN the lanes while `on` holds (lane 0 is never on) */
+    auto run_down = [&](const bool on, const int from) -> int {
+        const unsigned long long inv = ~__builtin_amdgcn_ballot_w64(on) << (63 - from);
+        return inv ? __builtin_clzll(inv) : 64;
+    };
+    /* (r, c) = the walker's window cell.  Decision of the cell of the walker's diagonal in this lane's column: 0 diagonal, 1 up, 2 left, 3 stop /
+     * other (ANW: the SCORING state's 1 = to INSERTION, 2 = to DELETION); lanes outside the window's usable part decide 3 */
+    auto decide_diag = [&](const int r, const int c, int &qcOut) -> uint32_t {
+        const int rr = r - (c - lane);
+        const bool usable = lane <= c && lane >= 1 && rr >= 1;
+        const int rq = usable ? rr : 1, cq = usable ? lane : 1; /* (clamped: every lane reads inside the window) */
+        const int qc = __builtin_amdgcn_ds_bpermute(rq << 2, (int)chQ);
+        qcOut = qc;
+        const int ii = R0 + 1 + rq, jc = cLo + cq;
+        uint32_t d;
+        if constexpr (PLANES == 1) {
+            const int h = cell(0, cq, rq), up = cell(0, cq, rq - 1), left = cell(0, cq - 1, rq);
+            if (algo == DPX_K_LSW) {
+                d = h <= 0 ? 3u : (up + g == h ? 1u : (left + g == h ? 2u : 0u)); /* UPPER, LEFT, CORNER; stop at 0 (c++/backtrack.cpp:21-97) */
             } else {
-                const int vh = c[-kWinCols], vdd = c[2 * kWinPlane - kWinCols], vq = wq[i - R0 - 1];
-                const int hu = rfl(vh), du = rfl(vdd), qc = rfl(vq);
-                if (i == 1 || hu + g + ext >= du + ext) cur = 0;
-                EMITW('_', ' ', qc); i--;
+                const int dg = cell(0, cq - 1, rq - 1);
+                const int mm = dg + ((uint32_t)qc == chR ? match : mismatch);
+                const int del = up + g, ins = left + g;
+                d = ins >= max(del, mm) ? 2u : (del >= mm ? 1u : 0u); /* INSERTION over DELETION over the diagonal */
+                if (ii == 0) d = 2u;       /* row 0: QUERY_INSERTION to the corner */
+                else if (jc == 0) d = 1u;  /* column 0: QUERY_DELETION */
+            }
+        } else {
+            const int dg = cell(0, cq - 1, rq - 1), I = cell(1, cq, rq), D = cell(2, cq, rq);
+            const int mm = dg + ((uint32_t)qc == chR ? match : mismatch);
+            d = I >= max(D, mm) ? 1u : (D >= mm ? 2u : 0u);
+            if (ii <= 0 || jc <= 0) d = 3u;
+        }
+        return usable ? d : 3u;
+    };
+    /* the lanes c, c-1, ... c-len+1 store the characters of a diagonal run (their own column's reference character, their row's query character) */
+    auto emit_diag = [&](const int c, const int len, const int qc) {
+        const int k = c - lane;
+        if (k >= 0 && k < len) {
+            const int at = pos - 1 - k;
+            lr[at] = (char)chR; lx[at] = ((uint32_t)qc == chR) ? '*' : '|'; lq[at] = (char)qc;
+        }
+        pos -= len;
+    };
+    /* `len` steps to the left from column c: the lanes store their reference characters against gaps */
+    auto emit_left = [&](const int c, const int len) {
+        const int k = c - lane;
+        if (k >= 0 && k < len) { const int at = pos - 1 - k; lr[at] = (char)chR; lx[at] = ' '; lq[at] = '_'; }
+        pos -= len;
+    };
+    /* `len` steps up from row r: lane k stores the query character of row r - k */
+    auto emit_up = [&](const int r, const int len) {
+        const int qc = __builtin_amdgcn_ds_bpermute(max(r - lane, 0) << 2, (int)chQ);
+        if (lane < len) { const int at = pos - 1 - lane; lr[at] = '_'; lx[at] = ' '; lq[at] = (char)qc; }
+        pos -= len;
+    };
+    int cur = 0; /* ANW: 0 SCORING, 1 INSERTION, 2 DELETION */
+    for (;;) {
+        if (algo == DPX_K_LSW ? !(i > 0 && j > 0) : !(i != 0 || j != 0)) break;
+        if (need_window()) load_window(max(i, 1), max(j, 1)); /* (a window anchored on row 1 / column 1 also serves row 0 / column 0) */
+        const int r = i - R0 - 1, c = j - cLo;
+        if constexpr (PLANES == 1) {
+            int qc;
+            const uint32_t d = decide_diag(r, c, qc);
+            const int run = run_down(d == 0u, c);
+            if (run) { emit_diag(c, run, qc); i -= run; j -= run; continue; }
+            const uint32_t dc = (uint32_t)__builtin_amdgcn_readlane((int)d, c);
+            if (algo == DPX_K_LSW && dc == 3u) break;
+            if (dc == 1u) { emit_up(r, 1); i--; }
+            else { emit_left(c, 1); j--; }
+        } else {
+            if (i == 0 || j == 0) { /* along a border to the corner: first up column 0, then left along row 0 (c++/backtrack.cpp:214-356) */
+                if (i > 0) { const int len = min(i, r); emit_up(r, len); i -= len; }   /* (rows r, r-1, ... 1 of the window hold query rows) */
+                else { const int len = min(j, c); emit_left(c, len); j -= len; }
+                continue;
+            }
+            if (cur == 0) {
+                int qc;
+                const uint32_t d = decide_diag(r, c, qc);
+                const int run = run_down(d == 0u, c);
+                if (run) { emit_diag(c, run, qc); i -= run; j -= run; continue; }
+                cur = __builtin_amdgcn_readlane((int)d, c); /* 1: to INSERTION, 2: to DELETION */
+            } else if (cur == 1) {
+                /* INSERTION: steps to the left along row r until (and including) the cell where the gap was opened; lane l decides the cell in column l */
+                const int cq = max(lane, 1), jc = cLo + cq;
+                const bool opened = jc == 1 || cell(0, cq - 1, r) + g + ext >= cell(1, cq - 1, r) + ext;
+                const bool usable = lane <= c && lane >= 1 && jc >= 1;
+                const int cont = run_down(usable && !opened, c);          /* cells the gap passes through */
+                const bool stops = c - cont >= 1 && cLo + c - cont >= 1;  /* ... and then a usable cell that opened it (else: the window's edge) */
+                const int len = cont + (stops ? 1 : 0);
+                emit_left(c, len); j -= len;
+                if (stops) cur = 0;
+            } else {
+                /* DELETION: steps up along column c; lane k decides the cell k rows above the walker */
+                const int rq = max(r - lane, 1), ii = R0 + 1 + rq;
+                const bool opened = ii == 1 || cell(0, c, rq - 1) + g + ext >= cell(2, c, rq - 1) + ext;
+                const bool usable = r - lane >= 1 && ii >= 1;
+                const unsigned long long m64 = __builtin_amdgcn_ballot_w64(!(usable && !opened)); /* first lane that ends the run: opened, or not usable */
+                const int cont = m64 ? __builtin_ctzll(m64) : 64;
+                const bool stops = r - cont >= 1 && R0 + 1 + r - cont >= 1;
+                const int len = cont + (stops ? 1 : 0);
+                emit_up(r, len); i -= len;
+                if (stops) cur = 0;
             }
         }
-        while (i > 0 || j > 0) { /* along a border to the corner */
-            if (need_window()) load_window(max(i, 1), max(j, 1));
-            if (i > 0) { const int qc = rfl((int)wq[i - R0 - 1]); EMITW('_', ' ', qc); i--; }
-            else { const int rc = rfl((int)wr[j - cLo]); EMITW(rc, ' ', '_'); j--; }
-        }
     }
-#undef EMITW
-    if (lane == 0) {
-        if (pos & 3) {
-            const int left = 4 - (pos & 3);
-            for (int t = 0; t < left; t++) {
-                lr[pos + t] = (char)(accR >> (8 * t)); lx[pos + t] = (char)(accX >> (8 * t)); lq[pos + t] = (char)(accQ >> (8 * t));
-            }
-        }
-        tbLen[p] = cap - pos;
-    }
+    if (lane == 0) tbLen[p] = cap - pos;
 }
 
 /* =====================================================================================================

@@ -8,12 +8,16 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-device 0] [-noprint] [-pack2] [-producer 0|1] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-device 0] [-noprint] [-pack2] [-producer 0|1] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
-// V14.cu:144-213 -- 10000 pairs of 1024 x 1024 would be a 22 GB pool whose allocation costs 50 times the fill).  Two such
-// pools are built on a helper thread while the file is being parsed and then recycled by every batch.
+// V14.cu:144-213 -- 10000 pairs of 1024 x 1024 would be a 22 GB pool whose allocation costs 50 times the fill).  -inflight such
+// pools (default 6, at most 8) are built on a helper thread while the file is being parsed and then recycled by every batch: that many
+// batches are on the device at a time.  Round 4 (profiles/r04/e2e_long_timeline_*.txt): a batch of 1700 pairs of 1024 x 1024 is a chain
+// of latency-bound kernels -- its fill keeps 0.8 waves per SIMD busy for 0.6 ms, the walks of its traceback 1.7 waves for 0.5 ms --
+// and with two batches in flight the device idled between the chains (9.1 ms for 10 000 pairs, of which the device worked 7.5); with
+// six the fills of the later batches run under the tracebacks of the earlier ones.
 //
 // Multi-GPU: pairs are independent, so every GPU gets one process with its own contiguous shard of the file:
 // `-rank r -world w` aligns only pairs [ceil(N/w)*r, ceil(N/w)*(r+1)) (the same split as shard.py / bench.py) and
@@ -60,6 +64,7 @@ int main(int argc, char *argv[]) {
     double poolGb = 4.0;
     bool print = true, pack2 = false;
     int producerFlag = -1; // -1: by batch size
+    int inflight = 2;      // batches on the device at a time (= matrix pools reserved)
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -79,6 +84,7 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-noprint")) print = false;
         else if (!strcmp(argv[i], "-pack2")) pack2 = true;
         else if (!strcmp(argv[i], "-producer")) producerFlag = atoi(next("-producer"));
+        else if (!strcmp(argv[i], "-inflight")) inflight = atoi(next("-inflight"));
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
@@ -86,6 +92,7 @@ int main(int argc, char *argv[]) {
     if (!pairFileName) { fprintf(stderr, "need -pairs <file>\n"); exit(EXIT_FAILURE); }
     if (poolGb < 0.0625 || poolGb > 200) { fprintf(stderr, "bad -pool-gb\n"); exit(EXIT_FAILURE); }
     if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "bad -rank/-world\n"); exit(EXIT_FAILURE); }
+    if (inflight < 1 || inflight > 8) { fprintf(stderr, "bad -inflight (1..8)\n"); exit(EXIT_FAILURE); }
     const int algo = algoName == "LNW" ? DPX_ALGO_LNW : algoName == "LSW" ? DPX_ALGO_LSW : algoName == "ANW" ? DPX_ALGO_ANW
                      : algoName == "BSW" ? DPX_ALGO_BSW : -1;
     if (algo < 0) { fprintf(stderr, "unknown -algo %s\n", algoName.c_str()); exit(EXIT_FAILURE); }
@@ -108,7 +115,7 @@ int main(int argc, char *argv[]) {
     const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
     std::thread reserve;
     // (and three pinned text buffers: one being printed, two batches in flight)
-    if (batchSize == 0) reserve = std::thread([poolBudget, print]() { (void)dpx_pool_reserve(poolBudget, 2); if (print) (void)dpx_text_reserve((size_t)16 << 20, 3); });
+    if (batchSize == 0) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 1); });
 
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;
@@ -127,6 +134,8 @@ int main(int argc, char *argv[]) {
         const double perPair = 2.0 * (algo == DPX_ALGO_ANW ? 3 : 1) * ((double)fileInfo.maxQueryLength + 64) * cols;
         const double fit = (double)poolBudget / (perPair > 0 ? perPair : 1);
         batchSize = (size_t)std::min(20000.0, std::max(64.0, fit));
+        batchSize &= ~(size_t)1; // even: the packed kernels fill COUPLES of equal-shaped pairs, an odd batch leaves one pair to a second kernel
+                                 // of one wave (0.4 ms of latency on 1024 x 1024, and on a shared hardware queue the couples' kernel waits for it)
     }
     // -pack2: the parse step emits four bases per byte (alphabets of up to four symbols); the batches then move a quarter of the
     // sequence bytes to the device, which expands them (dpx_batch_create_packed2).  Like parsing, outside the timer.
@@ -182,7 +191,7 @@ int main(int argc, char *argv[]) {
     // One batch: create, fill, start the output.  Two batches alive need two matrix pools.  Allocating tens of GB costs hundreds of
     // ms (more than the overlap of one batch's traceback with the next batch's fill can ever win back), so batches with pools of
     // 16 GiB or more (an explicit -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
-    size_t maxAlive = 2;
+    size_t maxAlive = (size_t)inflight;
     uint64_t create_time = 0; // written by the thread that produces, read after it is done
     auto produce = [&](size_t first) -> InFlight {
         InFlight next;
@@ -246,15 +255,15 @@ int main(int argc, char *argv[]) {
         }
         producer.join();
     } else {
+        std::deque<InFlight> alive; // issued to the device, oldest first
         for (size_t first = shardLo; first < shardHi; first += batchSize) {
-            const InFlight next = produce(first);
-            if (filling.b) finish(filling); // the previous batch: by now the device has had a whole batch of head start
-            filling = next;
-            if (pool_is_huge(filling)) finish(filling);
+            if (alive.size() >= maxAlive) { finish(alive.front()); alive.pop_front(); } // (its pool is parked for the batch produced next)
+            alive.push_back(produce(first));
+            if (pool_is_huge(alive.back())) maxAlive = 1;
         }
+        while (!alive.empty()) { finish(alive.front()); alive.pop_front(); }
     }
     memalloc_time += create_time;
-    if (filling.b) finish(filling);
     retire_printed();
     fflush(stdout);
 

@@ -94,11 +94,11 @@ int dpx_device_count(int *count);
 /* name (<=255 chars), CU count, HBM bytes of the bound device; any pointer may be NULL */
 int dpx_device_info(char *name, size_t nameCap, int *computeUnits, size_t *hbmBytes);
 int dpx_shutdown(void);
-/* Allocate `count` (1 or 2) matrix pools of `bytes` each on the default device and park them for the batches to come (any batch
+/* Allocate `count` (1..8; one if `bytes` >= 16 GiB) matrix pools of `bytes` each on the default device and park them for the batches to come (any batch
  * whose matrices fit takes a parked pool instead of allocating), together with two streams per pool for those batches.  Meant for a helper thread while the caller parses its input:
  * the reference sizes its device buffers once, before the batch loop (cuda/LNW/LinearNeedlemanWunschV14.cu:144-213). */
 int dpx_pool_reserve(size_t bytes, int count);
-/* The same for `count` (1..4) pinned host buffers of `bytes` (<= 1 GiB) each, which the result text of the batches to come is copied
+/* The same for `count` (1..9) pinned host buffers of `bytes` (<= 1 GiB) each, which the result text of the batches to come is copied
  * into (dpx_batch_output_end / _take; a parked buffer of up to 32 MiB serves any text of 2 MiB or more that fits). */
 int dpx_text_reserve(size_t bytes, int count);
 const char *dpx_strerror(int status);

@@ -74,7 +74,7 @@ def test_reserved_pools_serve_the_batches_that_follow(gpu):
     lib = gpu.load()
     lib.dpx_shutdown(); gpu.init(0)
     assert lib.dpx_pool_reserve(1 << 30, 2) == 0
-    assert lib.dpx_pool_reserve(0, 1) == -1 and lib.dpx_pool_reserve(1 << 20, 3) == -1   # DPX_ERR_INVALID
+    assert lib.dpx_pool_reserve(0, 1) == -1 and lib.dpx_pool_reserve(1 << 20, 9) == -1   # DPX_ERR_INVALID
     sb = make_batch(300, 512, 512, seed=23)
     with gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *W) as b1, gpu.Batch(gpu.ALGO_LSW, sb.sequences, sb.pairs, *W) as b2:
         for b in (b1, b2):                                       # two batches in flight: each took one of the two reserved pools
@@ -92,7 +92,7 @@ def test_reserved_text_buffers_serve_the_output_of_the_batches_that_follow(gpu):
     lib = gpu.load()
     lib.dpx_shutdown(); gpu.init(0)
     assert lib.dpx_text_reserve(16 << 20, 3) == 0
-    assert lib.dpx_text_reserve(0, 1) == -1 and lib.dpx_text_reserve(1 << 20, 5) == -1 and lib.dpx_text_reserve(2 << 30, 1) == -1   # DPX_ERR_INVALID
+    assert lib.dpx_text_reserve(0, 1) == -1 and lib.dpx_text_reserve(1 << 20, 10) == -1 and lib.dpx_text_reserve(2 << 30, 1) == -1   # DPX_ERR_INVALID
     big, small = make_batch(900, 700, 900, seed=24), make_batch(20, 60, 70, seed=25)                 # ~4.3 MB and ~8 KB of text
     texts = []
     for _ in range(2):

@@ -13,7 +13,7 @@ sb = make_ragged_batch($N, 80, 130, 100, 160, seed=6) if "$SHAPE" == "short" els
 dpx.write_pairs_file(sb, "/tmp/e2e_pairs.txt")
 PY
 make -s -C dpx_gpu_genomics_project_amd/hostcpp
-for algo in LSW LNW ANW; do
+for algo in ${ALGOS:-LSW LNW ANW}; do
   EXT=""; OPEN=-2; [ $algo = ANW ] && EXT="-extend -1" && OPEN=-3
   echo "== $algo $N pairs ($SHAPE), print to file"
   dpx_gpu_genomics_project_amd/hostcpp/dpx_main -pairs /tmp/e2e_pairs.txt -algo $algo -match 3 -mismatch -1 -open $OPEN $EXT $BATCHARG ${E2E_EXTRA:-} > /tmp/e2e_out.txt
