@@ -1799,11 +1799,6 @@ int dpx_batch_matrix(dpx_batch *b, size_t pair, int which, int16_t *out) {
  * already formatted as c++/main.cpp prints them, so a driver writes a batch with one fwrite) */
 
 /* stage 1, asynchronous on the batch's stream: kernels + D2H of the offsets / lengths */
-/* paths at least this long (m + n) are walked by one wave per pair through an LDS window (k_traceback_wave; DPX_TB_WAVE_MIN overrides) */
-static int wave_walk_min_path() {
-    static const int v = [] { const char *e = getenv("DPX_TB_WAVE_MIN"); return e ? std::max(0, atoi(e)) : 1500; }();
-    return v;
-}
 
 static int output_begin(dpx_batch *b, uint64_t firstNumber) {
     PhaseTrace trace;
@@ -1833,22 +1828,17 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         HIP_TRY(hipEventRecord(b->evOut0, b->stream));
     }
     if (!b->tbLinesValid) {
-        /* How to walk: one lane per pair -- through register-cached column vectors (walk 1) when there are enough lanes in flight
-         * to thrash L1/L2 between two steps of a lane (measured: 20k pairs 10 % slower, 100k pairs 25 % faster), cell by cell (walk
-         * 0) otherwise.  Walk 2 (one WAVE per pair with an LDS window, k_traceback_wave) is opt-in: it cuts the HBM round trips of
-         * a 1024 x 1024 path from 1100 to ~35, but 64 lanes repeating the walk cost more than that saves below ~1000 steps per
-         * path (5000 x 1024^2: 1.60 vs 1.83 ms LSW, 1.50 vs 1.53 LNW; 20k x 300^2: 1.30 vs 0.65 ms; 100k short reads: 2.1 vs
-         * 0.59 ms).  DPX_TB_WALK=0/1/2 forces one. */
+        /* How to walk (round 4, tools/tb_kernel.sh, kernel time alone; profiles/r04/traceback_walks.txt).  Walk 2 = one WAVE per pair
+         * (k_traceback_wave: runs of path steps decided by all lanes at once from an LDS window): LSW / LNW always -- 1000 x 512^2 0.13 vs
+         * 0.60 ms for one lane per pair, 16 000 x 512^2 0.50 vs 0.76, 20 000 x 300^2 0.36 vs 0.54, 100 000 short reads 0.33 vs 0.57 (LSW) /
+         * 0.71 vs 0.69 (LNW); ANW (three planes per window) up to 6000 pairs, or up to 20 000 pairs of long paths -- 1000 x 512^2 0.21 vs
+         * 1.16, 5000 x 1024^2 1.68 vs 2.51, but 20 000 x 300^2 1.75 vs 0.98 and 100 000 short reads 1.61 vs 0.98.  Walks 0 / 1 = one lane
+         * per pair, cell by cell / through register-cached column vectors (the latter from 64k pairs on: enough lanes in flight to thrash
+         * L1 / L2 between two steps of a lane).  Banded matrices: one lane per pair.  DPX_TB_WALK=0/1/2 forces one (tests). */
         int walk = b->numPairs >= 65536 ? 1 : 0;
-        /* long paths on layouts with 8-row column vectors: one wave per pair through an LDS window, one HBM round trip per ~32
-         * path steps instead of one per step (round 2: 5000 x 1024^2 LSW 1.60 vs 1.83 ms; loses below ~1000-step paths) */
-        /* (tools/tb_time.py p512, traceback + D2H of the lines, wave vs lane walk: 1000 x 512^2 0.49 vs 0.90 ms LSW, 0.60 vs 1.24 ANW; 4000 x 512^2
-         * 0.81 vs 1.09, 1.33 vs 1.40; 3000 x 700^2 0.96 vs 1.39; but 20 000 x 300^2 2.05 vs 1.64: from 900-step paths on, up to 16k pairs) */
-        if (b->kernelAlgo != DPX_ALGO_BSW &&
-            ((b->maxM + b->maxN >= wave_walk_min_path() && b->numPairs < 65536) ||
-             (!getenv("DPX_TB_WAVE_MIN") && b->maxM + b->maxN >= 900 && b->numPairs < 16384))) walk = 2;
+        if (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW) walk = 2;
+        else if (b->kernelAlgo == DPX_ALGO_ANW && (b->numPairs < 6000 || (b->maxM + b->maxN >= 1500 && b->numPairs < 20000))) walk = 2;
         if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
-        else if (const char *env = getenv("DPX_TB_CACHED")) walk = atoi(env) != 0 ? 1 : 0; /* (round-1 knob, tests) */
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
         b->tbLinesValid = true;
     }

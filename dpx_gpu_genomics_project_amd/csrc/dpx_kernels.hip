@@ -2947,6 +2947,9 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     };
     int i = __builtin_amdgcn_readfirstlane(endRow[p]), j = __builtin_amdgcn_readfirstlane(endCol[p]);
     int R0 = 1 << 28, cLo = 1 << 28;
+    int diag0 = 0;        /* LSW / LNW: i - j of the cell the window was anchored on */
+    bool banded = false;  /* ... and whether only the band around that diagonal was fetched */
+    bool wantFull = false; /* the walk left the last band sideways (a long gap): fetch whole columns next time */
     uint32_t chR = 0u, chQ = 0u; /* reference character of this lane's column; query character of window row `lane` */
     /* window with (ii, jj) in its bottom-right corner region */
     auto load_window = [&](const int ii, const int jj) {
@@ -2954,16 +2957,27 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
         R0 = gBase * 8;
         cLo = jj - 63;
         const int jc = cLo + lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the previous window's reads are done before it is overwritten */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); /* the previous window's reads are done before it is overwritten (LDS only: the walk's byte stores are not waited for) */
         __builtin_amdgcn_wave_barrier();
+        /* One plane (LSW / LNW): only a BAND of the window is fetched -- the three row groups of every column around the diagonal through the
+         * anchor (rows d-8 .. d+7 at least, d = the diagonal's row in that column).  The walk follows that diagonal or leaves it by a few
+         * gap steps; need_window() re-anchors when it is more than 7 rows above / 6 below.  In the wavefront-tiled layouts every column's
+         * piece lies in its own 64-byte sector, so 3 instead of 8 pieces per column are 3/8 of the traffic and of the requests (the
+         * traceback of 10 000 pairs of 1024 x 1024 read ~5 GB for paths that touch ~0.3 GB). */
+        constexpr int GL = PLANES == 1 ? 3 : G; /* row groups of a banded column */
+        diag0 = ii - jj;
+        banded = PLANES == 1 && !wantFull;
+        const int dl = (ii - R0 - 1) - 63 + lane;
+        const int gFirst = banded ? min(max((dl - 8) >> 3, 0), G - GL) : 0;
+        const int gCount = banded ? GL : G;
         u32x4 v[PLANES][G];
 #pragma unroll
         for (int pl = 0; pl < PLANES; pl++) {
 #pragma unroll
             for (int gi = 0; gi < G; gi++) { /* all loads in flight together */
-                const int grp = gBase + gi;
+                const int grp = gBase + gFirst + gi;
                 v[pl][gi] = u32x4{0u, 0u, 0u, 0u};
-                if (grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = piece(pl, grp, jc);
+                if (gi < gCount && grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = piece(pl, grp, jc);
             }
         }
         { const int qi = R0 + lane; chQ = (lane < WR && qi >= 0 && qi < m) ? qry[qi] : 0u; } /* query character of row R0 + 1 + lane */
@@ -2971,8 +2985,8 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
         if (algo != DPX_K_LSW) { /* the borders of H as cells: column 0 and row 0 (LSW: zeros, as loaded) */
 #pragma unroll
             for (int gi = 0; gi < G; gi++) {
-                const int grp = gBase + gi;
-                if (jc == 0 || grp < 0) {
+                const int grp = gBase + gFirst + gi;
+                if (gi < gCount && (jc == 0 || grp < 0)) {
                     uint32_t d[4];
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -2988,25 +3002,30 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
 #pragma unroll
         for (int pl = 0; pl < PLANES; pl++)
 #pragma unroll
-            for (int gi = 0; gi < G; gi++) *reinterpret_cast<u32x4 *>(win + (pl * 64 + lane) * CS + gi * 8) = v[pl][gi];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int gi = 0; gi < G; gi++)
+                if (gi < gCount) *reinterpret_cast<u32x4 *>(win + (pl * 64 + lane) * CS + (gFirst + gi) * 8) = v[pl][gi];
+        /* the two characters are needed HERE: without this the compiler waits for them (s_waitcnt vmcnt(0)) where the walk first uses them --
+         * in every trip of the loop, where the wait also covers the byte stores of the previous trips (3 us per trip, measured) */
+        asm volatile("" : "+v"(chQ), "+v"(chR));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
     /* rows i-1, i and columns j-1, j must lie inside the window (borders are cells of it) */
-    auto need_window = [&]() -> bool { return i - 1 <= R0 || i > R0 + WR || j - 1 < cLo || j > cLo + 63; };
+    auto need_window = [&]() -> bool {
+        if (i - 1 <= R0 || i > R0 + WR || j - 1 < cLo || j > cLo + 63) return true;
+        if (banded) { const int dev = (i - j) - diag0; if (dev < -7 || dev > 6) { wantFull = true; return true; } } /* outside the fetched band */
+        return false;
+    };
     auto cell = [&](const int pl, const int col, const int row) -> int { return (int)win[(pl * 64 + col) * CS + row]; };
     /* number of lanes that continue a run which starts at lane `from` and goes DOWN the lanes while `on` holds (lane 0 is never on) */
     auto run_down = [&](const bool on, const int from) -> int {
         const unsigned long long inv = ~__builtin_amdgcn_ballot_w64(on) << (63 - from);
         return inv ? __builtin_clzll(inv) : 64;
     };
-    /* (r, c) = the walker's window cell.  Decision of the cell of the walker's diagonal in this lane's column: 0 diagonal, 1 up, 2 left, 3 stop /
-     * other (ANW: the SCORING state's 1 = to INSERTION, 2 = to DELETION); lanes outside the window's usable part decide 3 */
-    auto decide_diag = [&](const int r, const int c, int &qcOut) -> uint32_t {
-        const int rr = r - (c - lane);
-        const bool usable = lane <= c && lane >= 1 && rr >= 1;
-        const int rq = usable ? rr : 1, cq = usable ? lane : 1; /* (clamped: every lane reads inside the window) */
+    /* Decision of window cell (rq, cq) (>= 1 each: callers clamp), rc = the reference character of its column: 0 diagonal, 1 up, 2 left,
+     * 3 stop / other (ANW: the SCORING state's 1 = to INSERTION, 2 = to DELETION).  qcOut = the query character of its row. */
+    auto decide_cell = [&](const int rq, const int cq, const uint32_t rc, int &qcOut) -> uint32_t {
         const int qc = __builtin_amdgcn_ds_bpermute(rq << 2, (int)chQ);
         qcOut = qc;
         const int ii = R0 + 1 + rq, jc = cLo + cq;
@@ -3017,7 +3036,7 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
                 d = h <= 0 ? 3u : (up + g == h ? 1u : (left + g == h ? 2u : 0u)); /* UPPER, LEFT, CORNER; stop at 0 (c++/backtrack.cpp:21-97) */
             } else {
                 const int dg = cell(0, cq - 1, rq - 1);
-                const int mm = dg + ((uint32_t)qc == chR ? match : mismatch);
+                const int mm = dg + ((uint32_t)qc == rc ? match : mismatch);
                 const int del = up + g, ins = left + g;
                 d = ins >= max(del, mm) ? 2u : (del >= mm ? 1u : 0u); /* INSERTION over DELETION over the diagonal */
                 if (ii == 0) d = 2u;       /* row 0: QUERY_INSERTION to the corner */
@@ -3025,11 +3044,34 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
             }
         } else {
             const int dg = cell(0, cq - 1, rq - 1), I = cell(1, cq, rq), D = cell(2, cq, rq);
-            const int mm = dg + ((uint32_t)qc == chR ? match : mismatch);
+            const int mm = dg + ((uint32_t)qc == rc ? match : mismatch);
             d = I >= max(D, mm) ? 1u : (D >= mm ? 2u : 0u);
             if (ii <= 0 || jc <= 0) d = 3u;
         }
+        return d;
+    };
+    /* (r, c) = the walker's window cell; lane l decides the cell of the walker's diagonal in its own column (3 outside the usable part) */
+    auto decide_diag = [&](const int r, const int c, int &qcOut) -> uint32_t {
+        const int rr = r - (c - lane);
+        const bool usable = lane <= c && lane >= 1 && rr >= 1;
+        const uint32_t d = decide_cell(usable ? rr : 1, usable ? lane : 1, chR, qcOut); /* (clamped: every lane reads inside the window) */
         return usable ? d : 3u;
+    };
+    /* LSW / LNW gaps in runs as well (round 4: the end gaps of a global alignment of short reads are 30 steps along one row): the cells to the
+     * left of the walker on its row (lane l: column l) or above it in its column (lane k: k rows up) that decide like it.  In a banded
+     * window a run ends where it leaves the fetched band (`dev` = the walker's distance from the anchor's diagonal). */
+    auto left_run = [&](const int r, const int c, const int dev) -> int {
+        int qc;
+        const bool usable = lane <= c && lane >= 1 && (!banded || dev + (c - lane) <= 6);
+        const uint32_t d = decide_cell(r, usable ? lane : 1, chR, qc);
+        return run_down(usable && d == 2u, c);
+    };
+    auto up_run = [&](const int r, const int c, const int dev) -> int {
+        int qc;
+        const bool usable = r - lane >= 1 && (!banded || dev - lane >= -7);
+        const uint32_t d = decide_cell(usable ? r - lane : 1, c, (uint32_t)__builtin_amdgcn_readlane((int)chR, c), qc);
+        const unsigned long long ends = __builtin_amdgcn_ballot_w64(!(usable && d == 1u));
+        return ends ? __builtin_ctzll(ends) : 64;
     };
     /* the lanes c, c-1, ... c-len+1 store the characters of a diagonal run (their own column's reference character, their row's query character) */
     auto emit_diag = [&](const int c, const int len, const int qc) {
@@ -3055,17 +3097,23 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     int cur = 0; /* ANW: 0 SCORING, 1 INSERTION, 2 DELETION */
     for (;;) {
         if (algo == DPX_K_LSW ? !(i > 0 && j > 0) : !(i != 0 || j != 0)) break;
-        if (need_window()) load_window(max(i, 1), max(j, 1)); /* (a window anchored on row 1 / column 1 also serves row 0 / column 0) */
+        if (need_window()) { load_window(max(i, 1), max(j, 1)); wantFull = false; } /* (a window anchored on row 1 / column 1 also serves row 0 / column 0) */
         const int r = i - R0 - 1, c = j - cLo;
         if constexpr (PLANES == 1) {
+            if (algo != DPX_K_LSW && (i == 0 || j == 0)) { /* LNW on a border: to the corner in runs (row 0: QUERY_INSERTION, column 0: QUERY_DELETION) */
+                if (i == 0) { const int len = min(j, c); emit_left(c, len); j -= len; }
+                else { const int len = min(i, r); emit_up(r, len); i -= len; }
+                continue;
+            }
             int qc;
             const uint32_t d = decide_diag(r, c, qc);
             const int run = run_down(d == 0u, c);
             if (run) { emit_diag(c, run, qc); i -= run; j -= run; continue; }
             const uint32_t dc = (uint32_t)__builtin_amdgcn_readlane((int)d, c);
             if (algo == DPX_K_LSW && dc == 3u) break;
-            if (dc == 1u) { emit_up(r, 1); i--; }
-            else { emit_left(c, 1); j--; }
+            const int dev = (i - j) - diag0;
+            if (dc == 1u) { const int len = max(up_run(r, c, dev), 1); emit_up(r, len); i -= len; }
+            else { const int len = max(left_run(r, c, dev), 1); emit_left(c, len); j -= len; }
         } else {
             if (i == 0 || j == 0) { /* along a border to the corner: first up column 0, then left along row 0 (c++/backtrack.cpp:214-356) */
                 if (i > 0) { const int len = min(i, r); emit_up(r, len); i -= len; }   /* (rows r, r-1, ... 1 of the window hold query rows) */
