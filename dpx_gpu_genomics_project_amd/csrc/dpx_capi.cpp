@@ -461,8 +461,6 @@ struct dpx_batch {
     dpx_fill_args args{};
     size_t ldsBytes = 0;
     /* packed two-pairs-per-wave path (LNW/LSW with matrices): couples of equal-shaped pairs + leftover singles */
-    bool streamed = false; /* uniform batch on the stream schedule (k_linear_stream) */
-    size_t streamLds = 0;
     bool packed = false;
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
     bool packed2 = false;  /* the sequences arrived as 2-bit codes (dpx_batch_create_packed2) */
@@ -1352,34 +1350,6 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     const size_t numSingles = (b->packed || b->lanePacked || b->splitPk) ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
-    /* stream schedule: uniform batches of a linear-gap algorithm with matrices (DPX_STREAM=0 turns it off) */
-    int numStreams = 0;
-    {
-        bool want = b->store && !b->packed && !b->lanePacked && !b->split && !ragged && numPairs > 0 && (kernelAlgo == DPX_ALGO_LNW || kernelAlgo == DPX_ALGO_LSW) &&
-                    b->pairs[0].m > 0 && b->pairs[0].n >= 128;
-        /* opt-in: bit-exact and 3 % fewer bytes written, but not faster than one launch-scheduled wave per pair -- the
-         * fill is bound by store instructions per CU-cycle either way (profiles/README.md) */
-        want = want && getenv("DPX_STREAM") && atoi(getenv("DPX_STREAM")) != 0;
-        if (want) {
-            hipDeviceProp_t prop;
-            int cus = 256;
-            if (hipGetDeviceProperties(&prop, t_device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            /* One stream per wave slot.  Whole workgroups per CU (the dispatcher deals workgroups round-robin, so CU j gets
-             * blocks j, j+CUs, ...): numStreams = CUs * 4 waves * k workgroups, k <= 4 (the LDS request caps residency at
-             * 4 workgroups per CU).  A ragged multiple (e.g. 3.26 workgroups per CU) measured 24 % slower: the CUs
-             * that get one workgroup more finish last while the others idle. */
-            size_t slots = (size_t)cus * 4;
-            if (const char *env = getenv("DPX_STREAM_RESIDENT")) { const int v = atoi(env); if (v >= 1) slots = (size_t)v; } /* tests */
-            const size_t k = std::min<size_t>(4, (numPairs + slots - 1) / slots);
-            numStreams = (int)std::min(numPairs, slots * k);
-            want = numPairs > (size_t)numStreams || getenv("DPX_STREAM_RESIDENT"); /* only worth it with >= 2 pairs per stream */
-            if (!want) numStreams = 0;
-        }
-        if (want) {
-            b->streamed = true;
-        }
-    }
-
     /* matrix placement (dpx_layout.h): pairs that are launched next to each other are interleaved chunk by chunk in
      * groups of `group` waves, so a group writes one compact moving window instead of `group` far-apart streams */
     if (b->store) {
@@ -1406,25 +1376,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                 off += maxChunks * (uint64_t)cnt * chunkElems + groupPadElems;
             }
         };
-        if (b->streamed) {
-            /* streams are interleaved in groups like pairs; inside a stream the pairs follow each other S*n chunks apart */
-            const uint64_t pairChunks = dpx_tiled_chunks(b->pairs[0].m, b->pairs[0].n, b->R) - 63u; /* S*n */
-            for (size_t s0 = 0; s0 < (size_t)numStreams; s0 += (size_t)group) {
-                const size_t cntS = std::min((size_t)group, (size_t)numStreams - s0);
-                uint64_t maxPairs = 0;
-                for (size_t g = 0; g < cntS; g++) {
-                    const size_t sidx = s0 + g;
-                    const uint64_t c = (numPairs - sidx + (size_t)numStreams - 1) / (size_t)numStreams;
-                    maxPairs = std::max(maxPairs, c);
-                    for (uint64_t ord = 0; ord < c; ord++) {
-                        dpx_pair_dev &pd = b->pairs[sidx + ord * (size_t)numStreams];
-                        pd.chunkStride = (uint32_t)(cntS * chunkElems);
-                        pd.matOff = off + (uint64_t)g * chunkElems + ord * pairChunks * pd.chunkStride;
-                    }
-                }
-                off += (maxPairs * pairChunks + 63u) * (uint64_t)cntS * chunkElems;
-            }
-        } else if (b->packed || b->splitPk) place(couples, (size_t)group * 2, chunkElems); /* one wave (workgroup) = two adjacent slots */
+        if (b->packed || b->splitPk) place(couples, (size_t)group * 2, chunkElems); /* one wave (workgroup) = two adjacent slots */
         else if (b->lanePacked) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
             const uint32_t stepElems = dpx_wtile_step_elems(b->R / 8, b->planes);
             for (const dpx_wave_desc &wd : waves) {
@@ -1439,8 +1391,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                 off += steps * (uint64_t)stepElems;
             }
         }
-        if (b->streamed) {
-        } else if (b->packed || b->lanePacked || b->splitPk || !singles.empty()) {
+        if (b->packed || b->lanePacked || b->splitPk || !singles.empty()) {
             place(singles, (size_t)group, chunkElems);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
@@ -1511,9 +1462,6 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     a.ldsEdge2Off = (uint32_t)edgeBytes;
     a.ldsRefOff = banded ? (uint32_t)qBytes : (uint32_t)(edgeBytes * nEdges);
     a.ldsQryOff = banded ? 0u : (uint32_t)(edgeBytes * nEdges + refBytes);
-    a.numStreams = numStreams;
-    a.uniM = numPairs ? b->pairs[0].m : 0;
-    a.uniN = numPairs ? b->pairs[0].n : 0;
     a.ldsBufStride = 0;
     a.rowTags = 0;
     /* big batches are bound by the bytes they write: their ramp steps store only the lines that hold cells (6 % fewer bytes at
@@ -1524,16 +1472,6 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         a.ldsRefOff = 512u;
         a.ldsQryOff = (uint32_t)(512 + align_up((size_t)b->maxN + 128 + 16, 16));
         a.ldsBufStride = (uint32_t)align_up((size_t)b->maxN + 2, 8);
-    }
-    if (b->streamed) { /* per wave: edge row + 2 x (reference [n+128] + query [m + 64R + 16]) */
-        const size_t refB = align_up((size_t)b->maxN + 128, 16), qB = align_up((size_t)b->maxM + 64 * 16 + 16, 16);
-        a.ldsRefOff = (uint32_t)edgeBytes;
-        a.ldsQryOff = (uint32_t)(edgeBytes + refB);
-        a.ldsBufStride = (uint32_t)(refB + qB);
-        a.ldsPerWave = (uint32_t)(edgeBytes + 2 * (refB + qB));
-        a.wavesPerBlock = 4; /* (persistent waves: one launch of numStreams waves) */
-        b->streamLds = std::max<size_t>((size_t)a.ldsPerWave * (DPX_FILL_THREADS / 64), kLdsFloor);
-        if (b->streamLds > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
     if (b->packed && banded) { /* packed band kernel: 2-byte query and reference entries (two chars each) */
         dpx_fill_args &k = b->pkArgs;
@@ -1648,8 +1586,6 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
         if (e == hipSuccess) e = dpx_launch_fill_split_packed(b->pkArgs, b->kernelAlgo, b->R, b->splitWaves, b->pkLdsBytes, s);
     } else if (b->split) {
         e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, s);
-    } else if (b->streamed) {
-        e = dpx_launch_fill_stream(b->args, b->kernelAlgo, b->R, b->streamLds, s);
     } else {
         e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, s);
     }
@@ -1966,11 +1902,11 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : b->streamed ? "k_linear_stream" : "k_linear_fill";
+                         : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
-    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu streams=%d row_tags=%d seq_input=%s waves_per_workgroup=%u",
+    int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu row_tags=%d seq_input=%s waves_per_workgroup=%u",
                        names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
-                       b->nWaves, b->nSingles, (int)b->args.numStreams, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes",
+                       b->nWaves, b->nSingles, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes",
                        (b->packed || b->lanePacked) ? b->pkArgs.wavesPerBlock : (b->split || b->splitPk) ? (unsigned)b->splitWaves : b->args.wavesPerBlock);
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;

@@ -33,9 +33,7 @@ typedef struct dpx_fill_args {
     uint32_t ldsEdge2Off;       /* ANW: offset of the second edge row (D) */
     uint32_t ldsRefOff;         /* offset of the staged reference characters */
     uint32_t ldsQryOff;         /* offset of the staged query characters (rolling multi-stripe path) */
-    /* stream schedule (uniform batches): wave s of numStreams fills pairs s, s+numStreams, ... back to back */
-    int32_t numStreams, uniM, uniN;
-    uint32_t ldsBufStride;      /* bytes between the two staged (reference, query) buffers */
+    uint32_t ldsBufStride;      /* split kernel: int16 elements between two edge rows */
     int32_t rowTags;            /* packed SW kernel: 1 = one (score, row-in-lane, column) key per pair and lane (needs max score * R + R-1 <= 65535),
                                    0 = one (score, column) key per pair and row */
     int32_t rampLines;          /* 1: skew-ramp steps store only the 128-byte lines that hold cells (byte-bound batches); 0: whole chunks */
@@ -50,7 +48,6 @@ int dpx_lanes_waves_per_block(int algo);
 hipError_t dpx_launch_fill_lanes_packed(const dpx_fill_args &a, int algo, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
-hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_banded_packed(const dpx_fill_args &a, int C, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,

@@ -789,174 +789,6 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes(const dpx_fil
 }
 
 /* =====================================================================================================
- * Stream schedule for uniform batches (all pairs m x n): the rolling idea carried across PAIRS.  numStreams waves are
- * launched (at most what the chip holds at once); wave s fills pairs s, s+numStreams, s+2*numStreams, ... and a lane
- * that finishes the last column of one pair starts the first column of the next pair on the following step.  The
- * 63-step skew ramp -- 5.8 % of all stores at 1024x1024 with one stripe per pair -- is then paid once per stream
- * instead of once per pair, and the bytes written equal the algorithmic bytes to within 2 %.  The host lays the
- * pairs of a stream out back to back (the next pair's block starts S*n chunks after this one's, overlapping its
- * 63 ramp-down chunks; the two pairs use disjoint lane slots there), so the store address is simply chunk G of
- * the stream for every lane.  Sequences are staged in LDS, double-buffered per pair.
- * ===================================================================================================== */
-template <int R, bool LOCAL>
-__global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_stream(const dpx_fill_args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sidx = blockIdx.x * (int)a.wavesPerBlock + wv; /* stream index (wave-uniform) */
-    const int NW = a.numStreams;
-    if (sidx >= NW || sidx >= a.numPairs) return;
-    const int cnt = (a.numPairs - sidx + NW - 1) / NW; /* pairs of this stream */
-    const int n = a.uniN, m = a.uniM;
-    const int match = a.match, mismatch = a.mismatch, gap = a.gapOpen;
-    const int S = dpx_tiled_stripes(m, R);
-    const int pairSteps = S * n;
-
-    unsigned char *my = smem + (size_t)wv * a.ldsPerWave;
-    int16_t *edge = reinterpret_cast<int16_t *>(my);   /* bottom row of the stripe above (only used when S > 1) */
-    unsigned char *refl0 = my + a.ldsRefOff;             /* buffer b: refl0 + b*ldsBufStride, character j at [63 + j] */
-    unsigned char *ql0 = my + a.ldsQryOff;               /* buffer b: ql0 + b*ldsBufStride, row i (0-based) at [i] */
-    auto pair_at = [&](const int ord) -> int {           /* batch index of this stream's ord-th pair */
-        const int idx = sidx + ord * NW;
-        return a.order ? a.order[idx] : idx;
-    };
-    auto stage = [&](const int ord) {                    /* copy pair ord's sequences into buffer ord & 1 */
-        const dpx_pair_dev pq = a.pairs[pair_at(ord)];
-        const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pq.refIdx);
-        const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pq.qryIdx);
-        unsigned char *rl = refl0 + (size_t)(ord & 1) * a.ldsBufStride, *ql = ql0 + (size_t)(ord & 1) * a.ldsBufStride;
-        for (int x = lane; x < n; x += 64) rl[64 + x] = ref[x]; /* (opt-in schedule: byte staging kept, both buffers share fixed offsets) */
-        for (int x = lane; x < m; x += 64) ql[x] = qry[x];
-    };
-    stage(0);
-    if (cnt > 1) stage(1);
-
-    const dpx_pair_dev first = a.pairs[pair_at(0)];
-    const size_t cs = first.chunkStride;
-    int16_t *tile = a.mat + first.matOff + (size_t)lane * (R < 8 ? R : 8);
-
-    LinState<R, LOCAL> st;
-    int bestv = 0, bestrow = 0, bestcol = 0; /* SW: this lane's best of the pair it is in */
-    int dv = 0, dr = 0, dc = 0;              /* SW: the lane's result for the pair it left last */
-    int row0 = lane * R;
-    int nrows = min(max(m - row0, 0), R);
-    int jl = 1 - lane, kl = 0, ol = 0;       /* this lane's column, stripe within the pair, pair ordinal */
-    {
-        const unsigned char *ql = ql0;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            st.qc[r] = (r < nrows) ? (int)ql[row0 + r] : 0x100;
-            st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
-            st.key[r] = 0u;
-        }
-        st.dtop = LOCAL ? 0 : row0 * gap;
-    }
-    /* lane 0's `up`: row-0 border on a pair's first stripe, else the edge row.  (c0, k0) = lane 0's column and stripe
-     * within its pair for the step being prefetched -- wave-uniform counters, no divisions in the loop */
-    int c0 = 1, k0 = 0;
-    auto e0_next = [&]() -> int {
-        const int v = (k0 == 0) ? (LOCAL ? 0 : c0 * gap) : (int)edge[c0];
-        if (++c0 > n) { c0 = 1; if (++k0 == S) k0 = 0; }
-        return v;
-    };
-    bool sw = false, newPair = false;
-    int rcN = refl0[63 + jl];
-    int e0N = e0_next();
-    int nextDone = pairSteps + 62; /* step in which lane 63 runs the last column of the stream's next unfinished pair */
-    int od = 0;                    /* ordinal of that pair */
-    const int total = cnt * pairSteps + 63;
-    const int lm = (m - 1 - (S - 1) * 64 * R) / R, rm = (m - 1 - (S - 1) * 64 * R) % R; /* owner of row m */
-
-    for (int T = 0; T < total; T++) {
-        const int rc = rcN, e0 = e0N;
-        { /* prefetch for step T+1 */
-            const bool wrap = jl >= n;
-            const int jn = wrap ? 1 : jl + 1;
-            const int on = (wrap && kl == S - 1) ? ol + 1 : ol;
-            rcN = (refl0 + (size_t)(on & 1) * a.ldsBufStride)[63 + jn];
-            e0N = e0_next();
-        }
-        const int upin = wave_shr1(st.Hl[R - 1], e0); /* before a switching lane resets its registers */
-        if (sw) {
-            if constexpr (LOCAL) lin_fold_keys<R, LOCAL>(st, row0, nrows, bestv, bestrow, bestcol);
-            if (newPair) { /* this lane has finished pair ol-1 */
-                if constexpr (LOCAL) {
-                    dv = bestv; dr = bestrow; dc = bestcol;
-                    bestv = 0; bestrow = 0; bestcol = 0;
-                } else if (lane == lm) { /* score = H[m][n] of the pair just left (LinearNeedlemanWunsch.cpp:176) */
-                    int v = st.Hl[0];
-#pragma unroll
-                    for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-                    const int pd = pair_at(ol - 1);
-                    a.score[pd] = v; a.endRow[pd] = m; a.endCol[pd] = n;
-                }
-            }
-            row0 = kl * 64 * R + lane * R;
-            nrows = min(max(m - row0, 0), R);
-            const unsigned char *ql = ql0 + (size_t)(ol & 1) * a.ldsBufStride;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                st.qc[r] = (r < nrows) ? (int)ql[row0 + r] : 0x100;
-                st.Hl[r] = LOCAL ? 0 : (row0 + 1 + r) * gap;
-                st.key[r] = 0u;
-            }
-            st.dtop = LOCAL ? 0 : row0 * gap;
-        }
-        if (jl >= 1 && ol < cnt && nrows > 0) {
-            lin_cells<R, LOCAL, true>(st, upin, rc, jl, match, mismatch, gap);
-            if (S > 1 && lane == 63 && kl + 1 < S) edge[jl] = (int16_t)st.Hl[R - 1];
-        }
-        {
-            uint32_t w[(R + 1) / 2];
-            lin_pack<R, LOCAL>(st, w);
-            store_words<R>(tile + (size_t)T * cs, w); /* chunk T of the stream, whole, every step */
-        }
-        sw = false;
-        newPair = false;
-        if (jl >= n) {
-            jl = 1;
-            sw = true;
-            if (++kl == S) { kl = 0; ol++; newPair = true; }
-        } else {
-            jl++;
-        }
-        /* wave-uniform: lane 63 has just finished pair `od` (its last column ran in this step) */
-        if (T == nextDone) {
-            if constexpr (LOCAL) {
-                /* lane 63 folds only at its switch next step: take its live values now (its newPair is set) */
-                int fv = dv, fr = dr, fc = dc;
-                if (lane == 63) {
-                    int bv = bestv, br = bestrow, bc = bestcol;
-                    lin_fold_keys<R, LOCAL>(st, row0, nrows, bv, br, bc);
-                    fv = bv; fr = br; fc = bc;
-                }
-                const unsigned long long mine = ((unsigned long long)(unsigned)fv << 32) | (unsigned)(0x7FFFFFFF - fr);
-                const unsigned long long top = wave_max_u64(mine);
-                const int pd = pair_at(od);
-                if ((int)(top >> 32) == 0) {
-                    if (lane == 0) { a.score[pd] = 0; a.endRow[pd] = 0; a.endCol[pd] = 0; }
-                } else if (mine == top) {
-                    a.score[pd] = fv; a.endRow[pd] = fr; a.endCol[pd] = fc;
-                }
-            }
-            if (od + 2 < cnt) stage(od + 2); /* buffer od & 1 is free now; pair od+2 starts >= 64 steps from here */
-            od++;
-            nextDone += pairSteps;
-        }
-    }
-    if constexpr (!LOCAL) {
-        /* a lane whose last column ran in the final step never reaches its switch: write the last pair's score here */
-        if (lane == lm && newPair) {
-            int v = st.Hl[0];
-#pragma unroll
-            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-            const int pd = pair_at(cnt - 1);
-            a.score[pd] = v; a.endRow[pd] = m; a.endCol[pd] = n;
-        }
-    }
-}
-
-/* =====================================================================================================
  * Split kernel for SMALL batches (BASELINE configs[1]: 1000 pairs of 512 x 512 -- one wave per pair leaves the chip with
  * one wave per SIMD, and a lone wave issues a vector instruction only every 4 cycles).  One workgroup per pair, one WAVE
  * PER STRIPE: wave w fills rows [w*64R, (w+1)*64R) with R = 4 (or 2), all stripes at the same time, wave w+1 running
@@ -3507,25 +3339,6 @@ hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R,
                          : launch_lanes_kernel(k_linear_split_pk<4, false>, a, grid, 64 * waves, ldsBytes, stream);
     default: return hipErrorInvalidValue;
     }
-}
-
-/* stream schedule (uniform batches): a.numStreams persistent waves, each fills its pairs back to back */
-hipError_t dpx_launch_fill_stream(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream) {
-    if (a.numPairs <= 0 || a.numStreams <= 0) return hipSuccess;
-    const int wavesPerBlock = (int)a.wavesPerBlock;
-    dim3 grid((unsigned)((a.numStreams + wavesPerBlock - 1) / wavesPerBlock));
-    const bool local = algo == DPX_K_LSW;
-#define DPX_STREAM_CASE(R_)                                                                                    \
-    case R_: return local ? launch_fill_kernel(k_linear_stream<R_, true>, a, grid, ldsBytes, stream)          \
-                          : launch_fill_kernel(k_linear_stream<R_, false>, a, grid, ldsBytes, stream);
-    switch (R) {
-        DPX_STREAM_CASE(2)
-        DPX_STREAM_CASE(4)
-        DPX_STREAM_CASE(8)
-        DPX_STREAM_CASE(16)
-    default: return hipErrorInvalidValue;
-    }
-#undef DPX_STREAM_CASE
 }
 
 /* packed two-pairs-per-wave linear fill: a.order = couples (2 ints each), a.numPairs = number of couples */

@@ -8,7 +8,7 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-device 0] [-noprint] [-pack2] [-producer 0|1] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-device 0] [-noprint] [-pack2] [-producer P] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
@@ -27,7 +27,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <map>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -63,7 +65,7 @@ int main(int argc, char *argv[]) {
     size_t batchSize = 0;     // 0: from the pool budget (the reference's BATCH_SIZE, V19.cu:9, assumes short reads)
     double poolGb = 4.0;
     bool print = true, pack2 = false;
-    int producerFlag = -1; // -1: by batch size
+    int producerFlag = -1; // producer threads; -1: by batch size (2 for batches of many short pairs, none for few long ones)
     int inflight = 2;      // batches on the device at a time (= matrix pools reserved)
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
@@ -115,7 +117,7 @@ int main(int argc, char *argv[]) {
     const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
     std::thread reserve;
     // (and three pinned text buffers: one being printed, two batches in flight)
-    if (batchSize == 0) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 1); });
+    if (batchSize == 0) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 3); });
 
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;
@@ -192,7 +194,7 @@ int main(int argc, char *argv[]) {
     // ms (more than the overlap of one batch's traceback with the next batch's fill can ever win back), so batches with pools of
     // 16 GiB or more (an explicit -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
     size_t maxAlive = (size_t)inflight;
-    uint64_t create_time = 0; // written by the thread that produces, read after it is done
+    std::atomic<uint64_t> create_time{0}; // summed over the threads that produce
     auto produce = [&](size_t first) -> InFlight {
         InFlight next;
         next.first = first;
@@ -211,49 +213,52 @@ int main(int argc, char *argv[]) {
     };
     auto pool_is_huge = [](const InFlight &f) { uint64_t mb = 0; dpx_batch_info(f.b, nullptr, nullptr, &mb, nullptr); return mb >= (16ull << 30); };
     // Batches of many short pairs are bound by the HOST (dpx_batch_create: 1.1-1.4 ms per 20000 pairs for validation, two counting
-    // sorts, the wave packing and the H2D copies, against 0.15 + 0.3 ms of kernels): a producer thread issues batch k+1 while this
-    // thread waits for batch k, takes its text and hands it to the printer (100k short reads: 12 -> 7.5 ms).  Batches of few long
-    // pairs are bound by the device, and there one issuing thread is as fast or faster (10000 x 1024^2: 8.1-8.9 vs 8.4-9.3 ms).
-    // -producer 0|1 overrides.
-    const bool threaded = producerFlag >= 0 ? producerFlag != 0 : batchSize >= 8192;
-    if (threaded) {
+    // sorts, the wave packing and the H2D copies, against 0.15 + 0.3 ms of kernels).  Round 3 moved that onto ONE producer thread
+    // (100k short reads: 12 -> 7.5 ms, of which 5.9 ms were still that thread creating five batches one after the other); batches are
+    // independent, so round 4 creates them on several threads (-producer P, default 2: 100k short reads 6.3 -> 5.9 ms LSW, 9.2 -> 8.1 ANW; three or four threads contend and lose again, profiles/r04/e2e_producers.txt): every thread takes the next batch index, creates
+    // and fills the batch and starts its output, this thread finishes the batches in input order.  At most -inflight batches exist
+    // between the one being finished and the newest one being created.  Batches of few long pairs are bound by the device, and there one
+    // issuing thread is as fast or faster (10000 x 1024^2: 8.1-8.9 vs 8.4-9.3 ms).  -producer 0 turns the threads off.
+    const int producers = producerFlag >= 0 ? std::min(producerFlag, 8) : (batchSize >= 8192 ? 2 : 0);
+    if (producers > 0) {
+        const size_t numBatches = (shardHi - shardLo + batchSize - 1) / batchSize;
+        if ((size_t)producers + 1 > maxAlive) maxAlive = std::min<size_t>(8, (size_t)producers + 1); // (every producer needs a slot of its own)
         std::mutex qm;
         std::condition_variable qcv;
-        std::deque<InFlight> ready;
-        size_t alive = 0;
-        bool produced = false;
-        std::thread producer([&]() {
-            for (size_t first = shardLo; first < shardHi; first += batchSize) {
-                {
-                    std::unique_lock<std::mutex> lk(qm);
-                    qcv.wait(lk, [&]() { return alive < maxAlive; });
+        std::map<size_t, InFlight> ready; // created, filling, not yet finished; by batch index
+        std::atomic<size_t> nextBatch{0};
+        size_t consumed = 0; // batches finished (and destroyed) so far
+        std::vector<std::thread> pool;
+        for (int t = 0; t < producers; t++)
+            pool.emplace_back([&]() {
+                (void)dpx_init(device); // (binds the device for this thread)
+                for (;;) {
+                    const size_t k = nextBatch.fetch_add(1);
+                    if (k >= numBatches) return;
+                    {
+                        std::unique_lock<std::mutex> lk(qm);
+                        qcv.wait(lk, [&]() { return k < consumed + maxAlive; });
+                    }
+                    const InFlight next = produce(shardLo + k * batchSize);
+                    std::lock_guard<std::mutex> lk(qm);
+                    if (pool_is_huge(next)) maxAlive = 1;
+                    ready[k] = next;
+                    qcv.notify_all();
                 }
-                const InFlight next = produce(first);
-                const bool huge = pool_is_huge(next);
-                std::lock_guard<std::mutex> lk(qm);
-                if (huge) maxAlive = 1;
-                ready.push_back(next);
-                alive++;
-                qcv.notify_all();
-            }
-            std::lock_guard<std::mutex> lk(qm);
-            produced = true;
-            qcv.notify_all();
-        });
-        for (;;) {
+            });
+        for (size_t k = 0; k < numBatches; k++) {
             {
                 std::unique_lock<std::mutex> lk(qm);
-                qcv.wait(lk, [&]() { return !ready.empty() || produced; });
-                if (ready.empty()) break;
-                filling = ready.front();
-                ready.pop_front();
+                qcv.wait(lk, [&]() { return ready.count(k) != 0; });
+                filling = ready[k];
+                ready.erase(k);
             }
-            finish(filling); // (destroys the batch: its pool is parked for the producer's next one)
+            finish(filling); // (destroys the batch: its pool is parked for the batches still to be created)
             std::lock_guard<std::mutex> lk(qm);
-            alive--;
+            consumed = k + 1;
             qcv.notify_all();
         }
-        producer.join();
+        for (std::thread &t : pool) t.join();
     } else {
         std::deque<InFlight> alive; // issued to the device, oldest first
         for (size_t first = shardLo; first < shardHi; first += batchSize) {
@@ -263,7 +268,7 @@ int main(int argc, char *argv[]) {
         }
         while (!alive.empty()) { finish(alive.front()); alive.pop_front(); }
     }
-    memalloc_time += create_time;
+    memalloc_time += create_time.load();
     retire_printed();
     fflush(stdout);
 
