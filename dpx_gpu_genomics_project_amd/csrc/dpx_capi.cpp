@@ -59,6 +59,52 @@ int bind_device(int device = -1) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* Development and test knobs.  The environment is read in ONE place, when dpx_init() binds a device and again at the start of every
+ * dpx_batch_create*() (the tests flip a knob between two batches of one process); everything else reads this snapshot.  -1 / 0 = not
+ * set.  None of them changes a result: they force or forbid a kernel family, change the launch shape or trace the runtime. */
+struct Knobs {
+    int rowsPerLane = 0;   /* DPX_R=2|4|8|16 */
+    int packed = -1;       /* DPX_PACKED=0|1: the two-pairs-per-wave int16 kernels */
+    int lanes = -1;        /* DPX_LANES=0|1: the lane-packed (several pairs per wave) kernels */
+    int lanesPk = -1;      /* DPX_LANES_PK=0: keep the lane-packed batches on the int32 kernels */
+    int split = -1;        /* DPX_SPLIT=0|1: one wave per stripe */
+    int rowTags = -1;      /* DPX_ROW_TAGS=0: per-row start-cell keys in the packed SW kernel */
+    int rampLines = -1;    /* DPX_RAMP_LINES=0|1: skew ramps store lines / whole chunks */
+    int wavesPerBlock = 0; /* DPX_WPB=1|4 */
+    int group = 0;         /* DPX_GROUP: pairs per interleaved block of the matrix layout */
+    int tbWalk = -1;       /* DPX_TB_WALK=0|1|2 */
+    int poolProbe = -1;    /* DPX_POOL_PROBE=0|1|2: nothing / time the pool / time + shop, whatever DPX_TUNE_PLACEMENT says */
+    bool poolMalloc = false;  /* DPX_POOL=malloc: one hipMalloc instead of the chunked virtual range */
+    size_t poolChunkBytes = 0; /* DPX_POOL_CHUNK_MB */
+    int poolGuard = 0;     /* DPX_POOL_GUARD: 1 = pattern band behind the matrices, 2 = "selftest" (the band is born damaged) */
+    bool trace = false, traceVmm = false; /* DPX_TRACE / DPX_TRACE_VMM: phase timings / pool mapping calls on stderr */
+};
+std::mutex g_knobsMu;
+Knobs g_knobs;
+void refresh_knobs() {
+    auto num = [](const char *name, int unset) { const char *e = getenv(name); return e ? atoi(e) : unset; };
+    Knobs k;
+    k.rowsPerLane = num("DPX_R", 0);
+    k.packed = num("DPX_PACKED", -1);
+    k.lanes = num("DPX_LANES", -1);
+    k.lanesPk = num("DPX_LANES_PK", -1);
+    k.split = num("DPX_SPLIT", -1);
+    k.rowTags = num("DPX_ROW_TAGS", -1);
+    k.rampLines = num("DPX_RAMP_LINES", -1);
+    k.wavesPerBlock = num("DPX_WPB", 0);
+    k.group = num("DPX_GROUP", 0);
+    k.tbWalk = num("DPX_TB_WALK", -1);
+    k.poolProbe = num("DPX_POOL_PROBE", -1);
+    { const char *e = getenv("DPX_POOL"); k.poolMalloc = e && !strcmp(e, "malloc"); }
+    { const long v = num("DPX_POOL_CHUNK_MB", 0); k.poolChunkBytes = v > 0 ? (size_t)v << 20 : 0; }
+    { const char *e = getenv("DPX_POOL_GUARD"); k.poolGuard = !e ? 0 : !strcmp(e, "selftest") ? 2 : 1; }
+    k.trace = getenv("DPX_TRACE") != nullptr;
+    k.traceVmm = getenv("DPX_TRACE_VMM") != nullptr;
+    std::lock_guard<std::mutex> lk(g_knobsMu);
+    g_knobs = k;
+}
+Knobs knobs() { std::lock_guard<std::mutex> lk(g_knobsMu); return g_knobs; }
+
 /* LDS request that caps residency at 16 fill waves per CU (9 KiB per wave of the workgroup) */
 constexpr size_t kLdsFloor = 36u * 1024u * (DPX_FILL_THREADS / 64) / 4;
 
@@ -106,7 +152,7 @@ size_t vmm_granularity(int device) {
     if (hipMemGetAllocationGranularity(&grec, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) { (void)hipGetLastError(); grec = 0; }
     size_t g = std::max<size_t>({gmin, grec, (size_t)2 << 20});
     while (g & (g - 1)) g += g & (~g + 1); /* up to a power of two (it is one on every runtime seen) */
-    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] device %d: allocation granularity minimum %zu recommended %zu -> %zu\n", device, gmin, grec, g); fflush(stderr); }
+    if (knobs().traceVmm) { fprintf(stderr, "[vmm] device %d: allocation granularity minimum %zu recommended %zu -> %zu\n", device, gmin, grec, g); fflush(stderr); }
     known[device] = g;
     return g;
 }
@@ -121,7 +167,7 @@ size_t vmm_granularity(int device) {
  * allocated (tools/pool_leak.py).  Every status is checked: on a failure the range stays in g_vmmRanges (nothing is freed twice, the
  * leak is visible) and the error is left in dpx_last_error(). */
 bool vmm_release(void *va, VmmRange &r, size_t mappedBytes) {
-    static const bool dbg = getenv("DPX_TRACE_VMM") != nullptr;
+    const bool dbg = knobs().traceVmm;
     if (dbg) { fprintf(stderr, "[vmm] release [%p, %p) mapped %zu chunks %zu\n", va, (void *)((char *)va + r.bytes), mappedBytes, r.chunks.size()); fflush(stderr); }
     int cur = -1;
     (void)hipGetDevice(&cur);
@@ -150,9 +196,9 @@ bool vmm_release(void *va, VmmRange &r, size_t mappedBytes) {
 }
 
 hipError_t pool_alloc(void **out, size_t bytes) {
-    /* (read on every call, not cached: tools/pool_ab.py alternates the variants inside one process; a pool is allocated once per batch size) */
-    const bool useMalloc = [] { const char *e = getenv("DPX_POOL"); return e && !strcmp(e, "malloc"); }();
-    const size_t chunkEnv = [] { const char *e = getenv("DPX_POOL_CHUNK_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
+    const Knobs kn = knobs();
+    const bool useMalloc = kn.poolMalloc;
+    const size_t chunkEnv = kn.poolChunkBytes;
     if (useMalloc || bytes < ((size_t)64 << 20) || t_device < 0) return hipMalloc(out, bytes);
     const size_t gran = vmm_granularity(t_device);
     size_t chunk = std::max(chunkEnv ? chunkEnv : (size_t)256 << 20, gran);
@@ -164,8 +210,7 @@ hipError_t pool_alloc(void **out, size_t bytes) {
     /* hipMemAddressReserve of ROCm 7.2 ignores its alignment argument (ranges come back 2-MiB aligned whatever is asked for:
      * profiles/r04/vmm_granularity_and_alignment.txt), so the range is reserved one chunk longer and the pool starts at the first
      * chunk-aligned address inside it: every chunk is mapped at a multiple of its own size */
-    size_t align = chunk;
-    if (const char *env = getenv("DPX_POOL_ALIGN_MB")) { const long v = atol(env); if (v > 0) { align = std::max((size_t)v << 20, gran); while (align & (align - 1)) align += align & (~align + 1); } }
+    const size_t align = chunk; /* (2 MiB, 256 MiB or 1 GiB: the fills do not care, profiles/r04/vmm_granularity_and_alignment.txt) */
     r.reservedBytes = r.bytes + align;
     r.reserved = nullptr;
     hipError_t e = hipMemAddressReserve(&r.reserved, r.reservedBytes, align, nullptr, 0);
@@ -195,14 +240,14 @@ hipError_t pool_alloc(void **out, size_t bytes) {
         e = hipMemSetAccess(va, r.bytes, &acc, 1);
     }
     if (e != hipSuccess) {
-        if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] building %p failed after %zu of %zu bytes mapped: %s\n", va, mapped, r.bytes, hipGetErrorString(e)); fflush(stderr); }
+        if (kn.traceVmm) { fprintf(stderr, "[vmm] building %p failed after %zu of %zu bytes mapped: %s\n", va, mapped, r.bytes, hipGetErrorString(e)); fflush(stderr); }
         (void)vmm_release(va, r, mapped);
         if (e == hipErrorOutOfMemory) return e;
         /* a runtime without (working) virtual-memory management: one hipMalloc, as before round 3 -- slower to write, never wrong */
         (void)hipGetLastError();
         return hipMalloc(out, bytes);
     }
-    if (getenv("DPX_TRACE_VMM")) { fprintf(stderr, "[vmm] alloc [%p, %p) chunks %zu of %zu MiB\n", va, (void *)((char *)va + r.bytes), r.chunks.size(), chunk >> 20); fflush(stderr); }
+    if (kn.traceVmm) { fprintf(stderr, "[vmm] alloc [%p, %p) chunks %zu of %zu MiB\n", va, (void *)((char *)va + r.bytes), r.chunks.size(), chunk >> 20); fflush(stderr); }
     { std::lock_guard<std::mutex> lk(g_vmmMu); g_vmmRanges.emplace(va, std::move(r)); }
     *out = va;
     return hipSuccess;
@@ -389,7 +434,7 @@ void trim_all_caches() {
 namespace {
 /* DPX_TRACE=1: phase timings of dpx_batch_create / destroy on stderr (development aid) */
 struct PhaseTrace {
-    bool on = getenv("DPX_TRACE") != nullptr;
+    bool on = knobs().trace;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void mark(const char *what) {
         if (!on) return;
@@ -465,8 +510,6 @@ struct dpx_batch {
     bool split = false;    /* small batch: one workgroup per pair, one wave per stripe (k_linear_split) */
     bool packed2 = false;  /* the sequences arrived as 2-bit codes (dpx_batch_create_packed2) */
     bool lanesPk = false;  /* lane-packed batch on k_linear_lanes_pk (two row blocks of a pair in the halves of every register) */
-    bool splitPk = false;  /* ... two equal-shaped pairs per workgroup on the packed-int16 pipe (k_linear_split_pk); leftovers on k_linear_split */
-    size_t splitPkLds = 0;
     int splitWaves = 0;
     size_t splitLds = 0;
     bool lanePacked = false; /* short queries: several pairs per wave (k_linear_lanes / k_affine_lanes, 8 x 8 tile layout); wave
@@ -524,6 +567,7 @@ int dpx_device_count(int *count) {
 }
 
 int dpx_init(int device) {
+    refresh_knobs();
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -804,9 +848,8 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s);
  * pairs = 238 workgroups 3265).  Small launches therefore use one-wave workgroups (the CUs differ by at most one wave); big ones keep
  * four (a few per cent faster there: fewer workgroups to dispatch, profiles/r03/ab_nontemporal_stores_and_wg64.txt).  DPX_WPB=1|4 forces one. */
 static uint32_t fill_waves_per_block(size_t waves) {
-    if (const char *env = getenv("DPX_WPB")) { const int v = atoi(env); if (v == 1 || v == 4) return (uint32_t)v; }
-    static const size_t small = [] { const char *e = getenv("DPX_WPB_SMALL"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)4096; }();
-    return waves <= small ? 1u : 4u;
+    { const int v = knobs().wavesPerBlock; if (v == 1 || v == 4) return (uint32_t)v; }
+    return waves <= 4096 ? 1u : 4u;
 }
 
 /* DPX_TUNE_PLACEMENT (callers that fill a resident batch many times: bench.py, iterative drivers).  The same fill runs up to
@@ -977,6 +1020,8 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     rc = bind_device(device);
     if (rc != DPX_OK) return rc;
 
+    refresh_knobs();
+    const Knobs kn = knobs();
     PhaseTrace trace;
     dpx_batch *b = new (std::nothrow) dpx_batch();
     if (!b) return DPX_ERR_NOMEM;
@@ -1013,8 +1058,8 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     /* linear gaps: 16 rows per lane once a query is longer than 512 (one stripe up to 1024 rows, two 1-KiB sub-tiles per
      * step: measured 4 % faster than 8 rows x 2 rolling stripes); the affine kernel carries three chains and stays at 8 */
     int R = b->maxM <= 128 ? 2 : b->maxM <= 256 ? 4 : (b->maxM <= 512 || params->algo == DPX_ALGO_ANW) ? 8 : 16;
-    if (const char *env = getenv("DPX_R")) {
-        int v = atoi(env);
+    if (kn.rowsPerLane) {
+        const int v = kn.rowsPerLane;
         if (v == 2 || v == 4 || v == 8 || (v == 16 && params->algo != DPX_ALGO_ANW)) R = v;
     }
     b->R = R;
@@ -1063,7 +1108,6 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     /* Store-bound fills run ~2 % faster with 3-4 waves per SIMD than with 6-7 (fewer write streams in flight,
      * profiles/README.md): cap residency at 4 workgroups per CU through the LDS request. */
     if (b->store && !banded && b->ldsBytes < kLdsFloor) b->ldsBytes = kLdsFloor;
-    if (const char *env = getenv("DPX_LDS_PAD")) b->ldsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
     if (b->ldsBytes > 160u * 1024u) { delete b; return DPX_ERR_UNSUPPORTED; }
 
 #define CREATE_TRY(call)                                                      \
@@ -1100,7 +1144,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                               pos(params->gapOpen) * ((long long)b->maxM + b->maxN);
         lanesPk = packed_safe(kp, b->maxM, b->maxN) && (-32768 - wmin + wmax <= lowest) &&
                   (kernelAlgo != DPX_ALGO_LSW || (top * 8 + 7 <= 65535 && params->gapOpen <= 0 && params->mismatch <= 0));
-        if (const char *env = getenv("DPX_LANES_PK")) lanesPk = lanesPk && atoi(env) != 0;
+        if (kn.lanesPk >= 0) lanesPk = lanesPk && kn.lanesPk != 0;
     }
     const int kLanesR = lanesPk ? 16 : lanes_rows(b->maxM, kernelAlgo);
     const bool lanesShape = lanesAlgo && b->maxM <= 64 * kLanesR && b->maxM > 0 && b->maxN <= 4096;
@@ -1109,8 +1153,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
      * per wave) 1074 vs 818 and 180x200 (23 lanes, two per wave) 395 vs 363: the path pays when the packing fills the lanes */
     bool useLanes = lanesShape && b->maxM <= 256 && numPairs >= 2048;
     bool lanesForced = false;
-    if (const char *env = getenv("DPX_LANES")) { useLanes = atoi(env) != 0 && lanesShape; lanesForced = true; }
-    else if (const char *env = getenv("DPX_QUAD")) { useLanes = atoi(env) != 0 && lanesShape; lanesForced = true; } /* (round-1 name of the knob) */
+    if (kn.lanes >= 0) { useLanes = kn.lanes != 0 && lanesShape; lanesForced = true; }
     std::vector<dpx_wave_desc> waves;
     size_t lanesRefArea = 0, lanesPairs = 0;
     if (useLanes) {
@@ -1165,7 +1208,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                      numPairs >= pkMinPairs;
     if (b->lanePacked) usePacked = false;
     else
-    if (const char *env = getenv("DPX_PACKED")) usePacked = atoi(env) != 0 && b->store && (linearAlgo || banded);
+    if (kn.packed >= 0) usePacked = kn.packed != 0 && b->store && (linearAlgo || banded);
     /* 16-bit wrapping arithmetic: only when weights and every intermediate provably fit (also under DPX_PACKED=1) */
     if (usePacked) {
         dpx_params kp = *params;
@@ -1210,8 +1253,9 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     {
         bool anyEmpty = false;
         for (size_t i = 0; i < numPairs && !anyEmpty; i++) anyEmpty = b->pairs[i].m <= 0 || b->pairs[i].n <= 0;
-        int sR = b->maxM > 256 ? 4 : 2; /* (queries over 4096 rows would need more than 16 stripes: not split) */
-        if (const char *env = getenv("DPX_SPLIT_R")) { const int v = atoi(env); if (v == 2 || v == 4) sR = v; } /* experiments: twice the stripes at 2 rows per lane */
+        /* (queries over 4096 rows would need more than 16 stripes: not split.  Twice the stripes at 2 rows per lane -- four waves per 512-row pair --
+         * lose: 1000 x 512^2 0.146 vs 0.120 ms, profiles/r04/configs1_split_variants.txt: the kernel is bound by its instruction stream, not by waves) */
+        const int sR = b->maxM > 256 ? 4 : 2;
         const int sW = dpx_tiled_stripes(b->maxM, sR);
         const size_t edgeStride = align_up((size_t)b->maxN + 2, 8); /* int16 elements */
         const size_t lds = 512 + align_up((size_t)b->maxN + 128 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgeStride * 2;
@@ -1226,55 +1270,16 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
          * 1173, 1000: 1943 vs 1932, 1500: 1987 vs 2060, 3000: 2446 vs 2744 -- queries that fit one stripe of the other kernels (<= 1024
          * rows) split only up to ~900 pairs (up to 512 rows: ~1100, a tie from there on); longer ones (the other kernels roll over several stripes) as before. */
         bool useSplit = shape && (b->maxM > 1024 ? (numPairs <= 1100 || (sW >= 4 && numPairs < 4096)) : numPairs <= (b->maxM > 512 ? 900u : 1100u));
-        if (const char *env = getenv("DPX_SPLIT")) useSplit = atoi(env) != 0 && shape;
+        if (kn.split >= 0) useSplit = kn.split != 0 && shape;
         if (useSplit) {
             b->split = true;
             b->R = sR;
             b->splitWaves = sW;
             b->splitLds = lds;
             for (size_t i = 0; i < numPairs; i++) { b->pairs[i].lanes = 32; b->pairs[i].rows = (uint16_t)sR; }
-            /* packed split kernel (round 3): couples of equal-shaped pairs, two per workgroup on the VOP3P pipe -- half the vector
-             * instructions per cell of a kernel that is bound by its instruction stream.  Needs the 16-bit wrapping adds to be safe
-             * (packed_safe) and, for SW, (score * R + R-1) to fit 16 bits (the row-tag keys). */
-            dpx_params kp = *params;
-            kp.algo = kernelAlgo;
-            auto pos = [](long long v) { return v > 0 ? v : 0; };
-            const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
-                                  pos(params->gapOpen) * ((long long)b->maxM + b->maxN);
-            const size_t edgePk = align_up((size_t)b->maxN + 2, 4); /* uint32 elements */
-            const size_t ldsPk = 1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16) + (size_t)std::max(sW - 1, 0) * edgePk * 4;
-            bool splitPk = numPairs >= 2 && packed_safe(kp, b->maxM, b->maxN) &&
-                           (kernelAlgo != DPX_ALGO_LSW || (top * sR + sR - 1 <= 65535 && params->gapOpen <= 0)) &&
-                           ldsPk <= 160u * 1024u;
-            /* measured (profiles/r03): 1000 x 512^2 0.170 vs 0.118 ms, 500 x 1024^2 +5 %, 2000 / 3000 x 1024^2 -1 % / -3 %: with about one
-             * wave per SIMD the fill is bound by the latency of a step, and a packed step is longer -- opt-in (DPX_SPLIT_PK=1) */
-            if (const char *env = getenv("DPX_SPLIT_PK")) splitPk = splitPk && atoi(env) != 0;
-            else splitPk = false;
-            if (splitPk) {
-                std::vector<int32_t> idx(numPairs);
-                std::iota(idx.begin(), idx.end(), 0);
-                if (ragged)
-                    std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) {
-                        const dpx_pair_dev &X = b->pairs[x], &Y = b->pairs[y];
-                        const uint64_t cx = (uint64_t)X.m * X.n, cy = (uint64_t)Y.m * Y.n;
-                        if (cx != cy) return cx > cy;
-                        if (X.m != Y.m) return X.m > Y.m;
-                        return X.n > Y.n;
-                    });
-                for (size_t i = 0; i < idx.size();) {
-                    if (i + 1 < idx.size() && b->pairs[idx[i]].m == b->pairs[idx[i + 1]].m && b->pairs[idx[i]].n == b->pairs[idx[i + 1]].n) {
-                        couples.push_back(idx[i]);
-                        couples.push_back(idx[i + 1]);
-                        i += 2;
-                    } else {
-                        singles.push_back(idx[i]);
-                        i += 1;
-                    }
-                }
-                b->splitPk = !couples.empty();
-                if (!b->splitPk) singles.clear();
-                b->splitPkLds = ldsPk;
-            }
+            /* (round 3's packed variant of this kernel -- couples of equal-shaped pairs, two per workgroup on the VOP3P pipe -- halved the waves as
+             * well as the instructions and lost wherever the split kernel is used: 1000 x 512^2 0.158 vs 0.119 ms, 2000 x 512^2 0.209 vs 0.206;
+             * deleted in round 4, profiles/r04/configs1_split_variants.txt) */
         }
     }
     trace.mark("create: validate+geometry+launch lists");
@@ -1333,7 +1338,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     if (b->lanePacked) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, waves.data(), waves.size() * sizeof(dpx_wave_desc), hipMemcpyHostToDevice));
-    } else if (b->packed || b->splitPk) {
+    } else if (b->packed) {
         b->dCouples = arenaCouples;
         CREATE_TRY(hipMemcpy(b->dCouples, couples.data(), couples.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     } else if (ragged) {
@@ -1347,22 +1352,20 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         b->dOrder = arenaOrder;
         CREATE_TRY(hipMemcpy(b->dOrder, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    const size_t numSingles = (b->packed || b->lanePacked || b->splitPk) ? singles.size() : numPairs;
+    const size_t numSingles = (b->packed || b->lanePacked) ? singles.size() : numPairs;
     const size_t numCouples = couples.size() / 2;
 
     /* matrix placement (dpx_layout.h): pairs that are launched next to each other are interleaved chunk by chunk in
      * groups of `group` waves, so a group writes one compact moving window instead of `group` far-apart streams */
     if (b->store) {
         int group = 64;
-        if (const char *env = getenv("DPX_GROUP")) { const int v = atoi(env); if (v >= 1 && v <= 1000000) group = v; }
+        if (kn.group >= 1 && kn.group <= 1000000) group = kn.group;
         const uint32_t chunkElems = (banded || b->split) ? 512u : dpx_tiled_chunk_elems(b->R, b->planes);
         auto chunksOf = [&](const dpx_pair_dev &pd) -> uint64_t {
             if (pd.lanes == 32) return dpx_split_chunks(pd.m, pd.n, b->R);
             return banded ? dpx_band_chunks(pd.m, pd.n, params->band) : dpx_tiled_chunks(pd.m, pd.n, b->R);
         };
         uint64_t off = 0;
-        uint64_t groupPadElems = 0; /* experiment: int16 elements left free behind every group's block (DPX_GROUP_PAD_KB) */
-        if (const char *env = getenv("DPX_GROUP_PAD_KB")) groupPadElems = (uint64_t)std::max(0, atoi(env)) * 512u;
         auto place = [&](const std::vector<int32_t> &slots, size_t slotsPerGroup, uint32_t chunkElems) { /* slots in launch order */
             for (size_t s0 = 0; s0 < slots.size(); s0 += slotsPerGroup) {
                 const size_t cnt = std::min(slotsPerGroup, slots.size() - s0);
@@ -1373,10 +1376,10 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                     pd.matOff = off + (uint64_t)g * chunkElems;
                     pd.chunkStride = (uint32_t)(cnt * chunkElems);
                 }
-                off += maxChunks * (uint64_t)cnt * chunkElems + groupPadElems;
+                off += maxChunks * (uint64_t)cnt * chunkElems;
             }
         };
-        if (b->packed || b->splitPk) place(couples, (size_t)group * 2, chunkElems); /* one wave (workgroup) = two adjacent slots */
+        if (b->packed) place(couples, (size_t)group * 2, chunkElems); /* one wave (workgroup) = two adjacent slots */
         else if (b->lanePacked) { /* tile layout (dpx_layout.h): every wave a contiguous stream of chunks, one per step; its pairs share the base */
             const uint32_t stepElems = dpx_wtile_step_elems(b->R / 8, b->planes);
             for (const dpx_wave_desc &wd : waves) {
@@ -1391,7 +1394,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
                 off += steps * (uint64_t)stepElems;
             }
         }
-        if (b->packed || b->lanePacked || b->splitPk || !singles.empty()) {
+        if (b->packed || b->lanePacked || !singles.empty()) {
             place(singles, (size_t)group, chunkElems);
         } else { /* launch order == pair order */
             std::vector<int32_t> ident(numPairs);
@@ -1415,11 +1418,11 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         bool fresh = false;
         /* DPX_POOL_GUARD=1 (tests): 4 MiB behind the matrices are filled with a pattern here and checked by dpx_batch_sync() -- a kernel that
          * writes past the end of the batch's matrices fails the test instead of hitting whatever is mapped behind the pool */
-        const bool guardOn = getenv("DPX_POOL_GUARD") != nullptr;
+        const bool guardOn = kn.poolGuard != 0;
         b->guardBytes = guardOn ? (size_t)4 << 20 : 0;
         CREATE_TRY(g_matCache.take(&pool, b->matElems * sizeof(int16_t) + b->guardBytes, &b->matPoolBytes, &fresh));
         if (b->guardBytes) CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t), 0xA5, b->guardBytes));
-        if (b->guardBytes && !strcmp(getenv("DPX_POOL_GUARD"), "selftest")) { /* (the checker's own test: one byte of the band is already wrong) */
+        if (b->guardBytes && kn.poolGuard == 2) { /* (the checker's own test: one byte of the band is already wrong) */
             CREATE_TRY(hipMemset((char *)pool + b->matElems * sizeof(int16_t) + 12345, 0, 1));
             b->guardSelfTest = true;
         }
@@ -1428,7 +1431,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
          * pool's size).  DPX_POOL_PROBE=0 / 1 / 2 forces nothing / timing only / timing + shopping, whatever the flag says */
         bool tune = (flags & DPX_TUNE_PLACEMENT) != 0;
         int probeEnv = -1;
-        if (const char *env = getenv("DPX_POOL_PROBE")) { probeEnv = atoi(env); tune = probeEnv != 0; }
+        if (kn.poolProbe >= 0) { probeEnv = kn.poolProbe; tune = probeEnv != 0; }
         PoolRecord rec;
         bool known = false;
         if (!fresh) {
@@ -1467,7 +1470,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
     /* big batches are bound by the bytes they write: their ramp steps store only the lines that hold cells (6 % fewer bytes at
      * 1024 x 1024: +3 % LSW, +5 % LNW); small ones are bound by step latency and keep the cheaper whole-chunk stores */
     a.rampLines = numPairs >= 2048 ? 1 : 0;
-    if (const char *env = getenv("DPX_RAMP_LINES")) a.rampLines = atoi(env) != 0;
+    if (kn.rampLines >= 0) a.rampLines = kn.rampLines != 0;
     if (b->split) { /* [control 512 B][staged reference][edge rows, one per stripe boundary] */
         a.ldsRefOff = 512u;
         a.ldsQryOff = (uint32_t)(512 + align_up((size_t)b->maxN + 128 + 16, 16));
@@ -1494,7 +1497,6 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         k.ldsPerWave = (uint32_t)(pkEdge + pkRef);
         k.ldsRefOff = (uint32_t)pkEdge;
         b->pkLdsBytes = (pkEdge + pkRef) * (DPX_FILL_THREADS / 64);
-        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env)); /* occupancy experiments */
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
         /* SW start cell: one (score, row-in-lane, column) key per pair and lane where score * R + R-1 provably fits 16 bits
          * (1024 x 1024 at match 3: 3072 * 16 + 15), else one (score, column) key per pair and row (32 more registers at R = 16) */
@@ -1503,7 +1505,7 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
             const long long top = pos(std::max<long long>(params->match, params->mismatch)) * std::min<long long>(b->maxM, b->maxN) +
                                   pos(params->gapOpen) * ((long long)b->maxM + b->maxN); /* fits_int16()'s bound on H */
             k.rowTags = (kernelAlgo == DPX_ALGO_LSW && top * b->R + b->R - 1 <= 65535 && params->gapOpen <= 0) ? 1 : 0; /* (gap <= 0: the saturating gap term) */
-            if (const char *env = getenv("DPX_ROW_TAGS")) k.rowTags = (atoi(env) != 0 && k.rowTags) ? 1 : 0; /* A/B runs: 0 = the per-row keys */
+            if (kn.rowTags >= 0) k.rowTags = (kn.rowTags != 0 && k.rowTags) ? 1 : 0; /* (tests: 0 = the per-row keys) */
         }
     }
     if (b->lanePacked) { /* per wave: the line stage of the writeback (dpx_kernels.hip: LineStage) + the staged references of its pairs */
@@ -1515,29 +1517,18 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         k.ldsPerWave = (uint32_t)(dpx_lanes_stage_bytes(kernelAlgo, kLanesR, b->store) + lanesRefArea);
         /* (the lane-packed kernels keep their four-wave workgroups at every size: 20 000 short reads 131-148 us against 150-153 with one-wave
          * workgroups, 100 000 the same; DPX_WPB=1 forces the latter) */
-        k.wavesPerBlock = kernelAlgo == DPX_ALGO_ANW ? 1u : (getenv("DPX_WPB") && atoi(getenv("DPX_WPB")) == 1 ? 1u : (uint32_t)dpx_lanes_waves_per_block(kernelAlgo));
+        k.wavesPerBlock = kernelAlgo == DPX_ALGO_ANW ? 1u : (kn.wavesPerBlock == 1 ? 1u : (uint32_t)dpx_lanes_waves_per_block(kernelAlgo));
         b->pkLdsBytes = (size_t)k.ldsPerWave * (size_t)k.wavesPerBlock;
-        if (const char *env = getenv("DPX_LDS_PAD")) b->pkLdsBytes += (size_t)std::max(0, atoi(env));
         if (b->pkLdsBytes > 160u * 1024u) { dpx_batch_destroy(b); return DPX_ERR_UNSUPPORTED; }
     }
-    if (b->splitPk) { /* packed split kernel: 1 KiB of control, 2-byte reference entries, 4-byte edge entries */
-        dpx_fill_args &k = b->pkArgs;
-        k = a;
-        k.order = b->dCouples;
-        k.numPairs = (int32_t)numCouples;
-        k.ldsRefOff = 1024u;
-        k.ldsQryOff = (uint32_t)(1024 + align_up(((size_t)b->maxN + 128) * 2 + 16, 16));
-        k.ldsBufStride = (uint32_t)align_up((size_t)b->maxN + 2, 4);
-        b->pkLdsBytes = b->splitPkLds;
-    }
-    if ((b->packed || b->lanePacked || b->splitPk) && numSingles > 0) {
+    if ((b->packed || b->lanePacked) && numSingles > 0) {
         /* more than one kernel per fill: a side stream + fork/join events (failure here only costs the overlap) */
         if (stream_take(&b->sideStream) != hipSuccess) { b->sideStream = nullptr; (void)hipGetLastError(); }
         if (b->sideStream && (hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming) != hipSuccess ||
                               hipEventCreateWithFlags(&b->evJoin, hipEventDisableTiming) != hipSuccess)) (void)hipGetLastError();
     }
     b->nSingles = numSingles;
-    b->nCouples = (b->packed || b->splitPk) ? numCouples : 0;
+    b->nCouples = b->packed ? numCouples : 0;
     b->nLanePairs = b->lanePacked ? lanesPairs : 0;
     b->nWaves = b->lanePacked ? waves.size() : 0;
     if (b->tuneShop && b->dMat && !b->guardBytes) {
@@ -1560,7 +1551,6 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
     int kernels = 0;
     if (b->packed) kernels++;
     if (b->lanePacked) kernels++;
-    if (b->splitPk) kernels++;
     if (hasMain) kernels++;
     hipStream_t side = s;
     bool forked = false;
@@ -1581,9 +1571,6 @@ static hipError_t launch_all(dpx_batch *b, hipStream_t s) {
         if (e == hipSuccess && hasMain) e = dpx_launch_fill(b->args, b->kernelAlgo, b->R, b->store, b->ldsBytes, side);
         if (e == hipSuccess) e = b->kernelAlgo == DPX_ALGO_BSW ? dpx_launch_banded_packed(b->pkArgs, b->R, b->pkLdsBytes, s)
                                                                : dpx_launch_fill_packed(b->pkArgs, b->kernelAlgo, b->R, b->pkLdsBytes, s);
-    } else if (b->splitPk) {
-        if (hasMain) e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, side); /* leftover singles */
-        if (e == hipSuccess) e = dpx_launch_fill_split_packed(b->pkArgs, b->kernelAlgo, b->R, b->splitWaves, b->pkLdsBytes, s);
     } else if (b->split) {
         e = dpx_launch_fill_split(b->args, b->kernelAlgo, b->R, b->splitWaves, b->splitLds, s);
     } else {
@@ -1774,7 +1761,7 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         int walk = b->numPairs >= 65536 ? 1 : 0;
         if (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW) walk = 2;
         else if (b->kernelAlgo == DPX_ALGO_ANW && (b->numPairs < 6000 || (b->maxM + b->maxN >= 1500 && b->numPairs < 20000))) walk = 2;
-        if (const char *env = getenv("DPX_TB_WALK")) walk = std::min(2, std::max(0, atoi(env)));
+        { const int w = knobs().tbWalk; if (w >= 0) walk = std::min(2, w); }
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
         b->tbLinesValid = true;
     }
@@ -1902,12 +1889,12 @@ int dpx_batch_describe(dpx_batch *b, char *buf, size_t cap) {
     if (!b || !buf || !cap) return DPX_ERR_INVALID;
     static const char *names[] = {"LNW", "LSW", "ANW", "BSW"};
     const char *kernel = b->kernelAlgo == DPX_ALGO_BSW ? (b->packed ? "k_banded_fill_pk" : "k_banded_fill") : b->kernelAlgo == DPX_ALGO_ANW ? (b->lanePacked ? "k_affine_lanes" : "k_affine_fill")
-                         : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->splitPk ? "k_linear_split_pk" : b->split ? "k_linear_split" : "k_linear_fill";
+                         : b->packed ? "k_linear_fill_pk" : b->lanesPk ? "k_linear_lanes_pk" : b->lanePacked ? "k_linear_lanes" : b->split ? "k_linear_split" : "k_linear_fill";
     /* dtype = the arithmetic type of the kernel that fills (most of) the batch */
     int len = snprintf(buf, cap, "algo=%s kernel_algo=%s kernel=%s dtype=%s rows_per_lane=%d store=%d couples=%zu lane_pairs=%zu waves=%zu singles=%zu row_tags=%d seq_input=%s waves_per_workgroup=%u",
-                       names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->splitPk || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
+                       names[b->prm.algo], names[b->kernelAlgo], kernel, (b->packed || b->lanesPk) ? "int16" : "int32", b->R, b->store ? 1 : 0, b->nCouples, b->nLanePairs,
                        b->nWaves, b->nSingles, (int)b->pkArgs.rowTags, b->packed2 ? "packed2" : "bytes",
-                       (b->packed || b->lanePacked) ? b->pkArgs.wavesPerBlock : (b->split || b->splitPk) ? (unsigned)b->splitWaves : b->args.wavesPerBlock);
+                       (b->packed || b->lanePacked) ? b->pkArgs.wavesPerBlock : b->split ? (unsigned)b->splitWaves : b->args.wavesPerBlock);
     if (b->dMat && len > 0 && (size_t)len < cap) { /* the matrix pool: how it was built, and the memset time of every candidate that was timed */
         const PoolRecord &r = b->poolRec;
         len += snprintf(buf + len, cap - (size_t)len, " pool=%s pool_bytes=%zu pool_chunk_mb=%zu pool_kept=%d pool_memset_ms=", r.mode.c_str(), b->matPoolBytes,

@@ -47,7 +47,6 @@ size_t dpx_lanes_stage_bytes(int algo, int R, bool store);
 int dpx_lanes_waves_per_block(int algo);
 hipError_t dpx_launch_fill_lanes_packed(const dpx_fill_args &a, int algo, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
-hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_banded_packed(const dpx_fill_args &a, int C, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_fill_packed(const dpx_fill_args &a, int algo, int R, size_t ldsBytes, hipStream_t stream);
 hipError_t dpx_launch_export(const int16_t *mat, const dpx_pair_dev &pr, int algo, int R, int planes, int plane, int gapOpen,

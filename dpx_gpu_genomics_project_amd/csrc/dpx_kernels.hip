@@ -1433,217 +1433,6 @@ __global__ void __launch_bounds__(DPX_FILL_THREADS) k_linear_lanes_pk(const dpx_
 }
 
 /* =====================================================================================================
- * Packed split kernel (round 3; BASELINE configs[1]: 1000 pairs of 512 x 512): k_linear_split's schedule -- one workgroup
- * per unit of work, one WAVE PER STRIPE, stripes concurrent, the stripe hand-off of cuda/LNW/LinearNeedlemanWunschV12.cu:
- * 110-113,141-143 through LDS edge rows -- with k_linear_fill_pk's arithmetic: the unit of work is a COUPLE of equal-shaped
- * pairs, pair A in the high half and pair B in the low half of every register (cuda/LNW/LinearNeedlemanWunschV18.cu:112-341),
- * the cell update on the VOP3P pipe.  The int32 split kernel is bound by its instruction stream (SQ counters, profiles/r03:
- * 62 % of all VALU issue slots at 1.5 waves per SIMD); this one issues half as many vector instructions per cell.
- * LDS: [control 512 B][reference: 2-byte entries, A char << 8 | B char][edge rows: 4-byte entries, one row per stripe boundary].
- * SW start cell: one (H * R + R-1 - row, column) key per pair and lane (pk_row_tag); a stripe that ends inside its 64 * R
- * rows masks the rows past the query's end (PARTIAL).  Matrices: the split layout (dpx_layout.h), one tile stream per pair.
- * ===================================================================================================== */
-template <int R>
-struct SplitPkState {
-    uint32_t Hl[R], qc[R], rowOk[R]; /* rowOk: 0xFFFFFFFF where the lane's row r exists (PARTIAL stripes only) */
-    uint32_t dtop, keyA, keyB;
-};
-
-template <int R, bool LOCAL, bool PARTIAL>
-__device__ __forceinline__ void split_pk_cells(SplitPkState<R> &st, const uint32_t upin, const uint32_t rcP, const int j, const uint32_t matchP,
-                                               const uint32_t negDeltaP, const uint32_t gapP) {
-    uint32_t u = upin, d = st.dtop, colMax = 0u;
-    const uint32_t onesP = 0x00010001u;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t left = st.Hl[r];
-        const uint32_t differs = dpx::pk_min_u16_raw(st.qc[r] ^ rcP, onesP);
-        const s16x2 sc = as_s16x2(dpx::pk_mad_i16_raw(differs, negDeltaP, matchP));
-        s16x2 h;
-        if constexpr (LOCAL) h = dpx::pk_max(pk_gap_sat(u, left, gapP), (s16x2)(as_s16x2(d) + sc)); /* gap <= 0 (host): gapP = |gap| */
-        else h = dpx::pk_max(dpx::pk_max(as_s16x2(u), as_s16x2(left)) + as_s16x2(gapP), (s16x2)(as_s16x2(d) + sc));
-        d = left;
-        u = as_u32(h);
-        st.Hl[r] = u;
-        if constexpr (LOCAL) {
-            uint32_t tg = pk_row_tag_of<R>(u, r);
-            if constexpr (PARTIAL) tg &= st.rowOk[r];
-            colMax = r == 0 ? tg : dpx::pk_max_u16_raw(colMax, tg);
-        }
-    }
-    if constexpr (LOCAL) {
-        const uint32_t negj = 0xFFFFu - (uint32_t)j;
-        st.keyA = max(st.keyA, (colMax & 0xFFFF0000u) | negj);
-        st.keyB = max(st.keyB, (colMax << 16) | negj);
-    }
-    st.dtop = upin;
-}
-
-template <int R, bool LOCAL>
-__global__ void __launch_bounds__(64 * DPX_SPLIT_MAX_WAVES) k_linear_split_pk(const dpx_fill_args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int G = 8 / R; /* steps per 16-byte store */
-    static_assert(R == 2 || R == 4, "rows per lane");
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int c = blockIdx.x;
-    const int pA = a.order[2 * c], pB = a.order[2 * c + 1];
-    const dpx_pair_dev prA = a.pairs[pA], prB = a.pairs[pB];
-    const int n = prA.n, m = prA.m; /* host guarantees prB.n == n, prB.m == m, both > 0 */
-    const int gap = a.gapOpen;
-    const uint32_t matchP = ((uint32_t)(uint16_t)a.match << 16) | (uint16_t)a.match;
-    const uint32_t negDeltaP = ((uint32_t)(uint16_t)(a.mismatch - a.match) << 16) | (uint16_t)(a.mismatch - a.match);
-    const int gapK = LOCAL ? -gap : gap; /* SW (gap <= 0, checked by the host): |gap| for the saturating gap term */
-    const uint32_t gapP = ((uint32_t)(uint16_t)gapK << 16) | (uint16_t)gapK;
-    const int W = dpx_tiled_stripes(m, R);
-    const unsigned char *refA = reinterpret_cast<const unsigned char *>(a.seq + prA.refIdx);
-    const unsigned char *refB = reinterpret_cast<const unsigned char *>(a.seq + prB.refIdx);
-    const unsigned char *qryA = reinterpret_cast<const unsigned char *>(a.seq + prA.qryIdx);
-    const unsigned char *qryB = reinterpret_cast<const unsigned char *>(a.seq + prB.qryIdx);
-    int *ctrl = reinterpret_cast<int *>(smem); /* 1 KiB of control: progress[16], arrivals at [16]; results from byte 128: 16 waves x 8 ints; dump at byte 640 */
-    int *result = ctrl + 32;
-    if (threadIdx.x < 32) ctrl[threadIdx.x] = 0;
-    uint16_t *refl = reinterpret_cast<uint16_t *>(smem + a.ldsRefOff); /* refl[64 + (j-1)] = A char << 8 | B char */
-    for (int x = 4 * (int)threadIdx.x; x < n; x += 4 * (int)blockDim.x) {
-        const uint32_t a4 = load4(refA + x), b4 = load4(refB + x);
-        uint2 v;
-        v.x = __builtin_amdgcn_perm(a4, b4, 0x05010400u);
-        v.y = __builtin_amdgcn_perm(a4, b4, 0x07030602u);
-        *reinterpret_cast<uint2 *>(refl + 64 + x) = v;
-    }
-    __syncthreads(); /* every wave of the workgroup is still here; surplus waves leave afterwards */
-    if (w >= W) return;
-    uint32_t *edgeMine = reinterpret_cast<uint32_t *>(smem + a.ldsQryOff) + (size_t)w * a.ldsBufStride; /* bottom row of this stripe (packed) */
-    const uint32_t *edgePrev = edgeMine - a.ldsBufStride;                                                /* ... of the stripe above */
-
-    const int row0 = w * 64 * R + lane * R;
-    const int nrows = min(max(m - row0, 0), R);
-    SplitPkState<R> st;
-    {
-        int qa[R], qb[R];
-        load_query_rows<R>(qa, qryA, row0, nrows);
-        load_query_rows<R>(qb, qryB, row0, nrows);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            st.qc[r] = ((uint32_t)qa[r] << 16) | (uint32_t)qb[r];
-            const uint16_t b = (uint16_t)(LOCAL ? 0 : (row0 + 1 + r) * gap);
-            st.Hl[r] = ((uint32_t)b << 16) | b;
-            st.rowOk[r] = r < nrows ? 0xFFFFFFFFu : 0u;
-        }
-        const uint16_t b = (uint16_t)(LOCAL ? 0 : row0 * gap);
-        st.dtop = ((uint32_t)b << 16) | b;
-        st.keyA = st.keyB = 0u;
-    }
-    const bool hasNext = w + 1 < W;
-    const int rowsHere = min(m - w * 64 * R, 64 * R);
-    const bool partial = rowsHere < 64 * R; /* wave-uniform */
-    const int storeLanes = min(64, (((rowsHere + R - 1) / R) + 7) & ~7);
-    const uint32_t SS = dpx_split_stripe_steps(n, R);
-    const size_t csA = prA.chunkStride, csB = prB.chunkStride;
-    int16_t *tileA = a.mat + prA.matOff + ((size_t)w * (SS / G)) * csA + (size_t)lane * 8;
-    int16_t *tileB = a.mat + prB.matOff + ((size_t)w * (SS / G)) * csB + (size_t)lane * 8;
-    const uint16_t *rp = refl + 64 - lane; /* rp[t] = reference characters of column j = t - lane + 1 */
-    auto wait_for = [&](const int need) __attribute__((always_inline)) {
-        while (__hip_atomic_load(&ctrl[w - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-    };
-    uint32_t *dump = reinterpret_cast<uint32_t *>(smem + 640); /* 16 entries: where lanes 0..62 put their copy of the edge write */
-    uint32_t accA[4], accB[4];
-    auto block16 = [&](const int tb, auto maskedTag, auto partialTag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(maskedTag)::value;
-        constexpr bool PARTIAL = decltype(partialTag)::value;
-        if (w > 0) wait_for(min(tb + 17, n));
-        uint32_t *ew = (hasNext && lane == 63) ? edgeMine + (tb - 62) : dump;
-        const uint16_t *rpb = rp + tb;
-        const uint32_t *epb = edgePrev + tb;
-        uint32_t rcN = rpb[0];
-        uint32_t bord = 0u; /* NW, first stripe: the packed row-0 border of the next column */
-        if constexpr (!LOCAL) { const uint16_t b = (uint16_t)((tb + 1) * gap); bord = ((uint32_t)b << 16) | b; }
-        uint32_t e0N = (w == 0) ? bord : epb[1];
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int t = tb + g;
-            const uint32_t rc16 = rcN, e0 = e0N;
-            rcN = rpb[g + 1];
-            if constexpr (!LOCAL) bord = as_u32((s16x2)(as_s16x2(bord) + as_s16x2(gapP)));
-            e0N = (w == 0) ? bord : epb[g + 2]; /* (entries past n are never used) */
-            const uint32_t rcP = __builtin_amdgcn_perm(0u, rc16, 0x0c010c00u);
-            const uint32_t upin = (uint32_t)wave_shr1((int)st.Hl[R - 1], (int)e0);
-            const int j = t - lane + 1;
-            if constexpr (MASKED) {
-                if (j >= 1 && j <= n) {
-                    split_pk_cells<R, LOCAL, PARTIAL>(st, upin, rcP, j, matchP, negDeltaP, gapP);
-                    if (hasNext && lane == 63) edgeMine[j] = st.Hl[R - 1];
-                }
-            } else {
-                split_pk_cells<R, LOCAL, PARTIAL>(st, upin, rcP, j, matchP, negDeltaP, gapP);
-                ew[g] = st.Hl[R - 1];
-            }
-            if constexpr (R == 4) {
-                accA[2 * (g % G)] = pk_hi16(st.Hl[0], st.Hl[1]); accA[2 * (g % G) + 1] = pk_hi16(st.Hl[2], st.Hl[3]);
-                accB[2 * (g % G)] = pack_lo16((int)st.Hl[0], (int)st.Hl[1]); accB[2 * (g % G) + 1] = pack_lo16((int)st.Hl[2], (int)st.Hl[3]);
-            } else {
-                accA[g % G] = pk_hi16(st.Hl[0], st.Hl[1]);
-                accB[g % G] = pack_lo16((int)st.Hl[0], (int)st.Hl[1]);
-            }
-            if ((g % G) == G - 1 && t - (G - 1) < n + 63) { /* whole lines, also on the skew ramps (every stripe owns its chunks) */
-                if (lane < storeLanes) {
-                    u32x4 va = {accA[0], accA[1], accA[2], accA[3]}, vb = {accB[0], accB[1], accB[2], accB[3]};
-                    stream_store(reinterpret_cast<u32x4 *>(tileA + (size_t)(t / G) * csA), va);
-                    stream_store(reinterpret_cast<u32x4 *>(tileB + (size_t)(t / G) * csB), vb);
-                }
-            }
-            if ((g & 7) == 7 && hasNext && t >= 63) {
-                if (lane == 63) __hip_atomic_store(&ctrl[w], min(t - 62, n), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    };
-    {
-        const int steps = (int)SS;
-        auto run = [&](auto partialTag) __attribute__((always_inline)) {
-            int tb = 0;
-            for (; tb < steps && tb < 64; tb += 16) block16(tb, std::true_type{}, partialTag);
-            for (; tb + 16 <= n; tb += 16) block16(tb, std::false_type{}, partialTag);
-            for (; tb < steps; tb += 16) block16(tb, std::true_type{}, partialTag);
-        };
-        if (partial) run(std::true_type{}); else run(std::false_type{});
-    }
-    if (hasNext && lane == 63) __hip_atomic_store(&ctrl[w], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-
-    if constexpr (LOCAL) {
-        constexpr int TB = R == 4 ? 2 : 1;
-        const int hA = (int)(st.keyA >> (16 + TB)), hB = (int)(st.keyB >> (16 + TB));
-        const int rA = row0 + R - (int)((st.keyA >> 16) & (R - 1)), rB = row0 + R - (int)((st.keyB >> 16) & (R - 1));
-        const unsigned long long mineA = ((unsigned long long)(unsigned)hA << 32) | (unsigned)(0x7FFFFFFF - rA);
-        const unsigned long long mineB = ((unsigned long long)(unsigned)hB << 32) | (unsigned)(0x7FFFFFFF - rB);
-        const unsigned long long topA = wave_max_u64(mineA), topB = wave_max_u64(mineB);
-        if (mineA == topA && (hA > 0 ? true : lane == 0)) { result[8 * w] = hA; result[8 * w + 1] = rA; result[8 * w + 2] = 0xFFFF - (int)(st.keyA & 0xFFFFu); }
-        if (mineB == topB && (hB > 0 ? true : lane == 0)) { result[8 * w + 4] = hB; result[8 * w + 5] = rB; result[8 * w + 6] = 0xFFFF - (int)(st.keyB & 0xFFFFu); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        int arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&ctrl[16], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived == W - 1 && lane < 2) { /* lane 0: pair A, lane 1: pair B -- max score, then the first stripe holding it */
-            int bv = 0, br = 0, bc = 0;
-            for (int k = 0; k < W; k++) {
-                const int v = __hip_atomic_load(&result[8 * k + 4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v > bv) { bv = v; br = result[8 * k + 4 * lane + 1]; bc = result[8 * k + 4 * lane + 2]; }
-            }
-            const int p = lane == 0 ? pA : pB;
-            a.score[p] = bv; a.endRow[p] = bv > 0 ? br : 0; a.endCol[p] = bv > 0 ? bc : 0;
-        }
-    } else {
-        const int lm = (m - 1 - w * 64 * R) / R, rm = (m - 1) % R; /* owner of row m (in the last stripe) */
-        if (w == W - 1 && lane == lm) {
-            uint32_t v = st.Hl[0];
-#pragma unroll
-            for (int r = 1; r < R; r++) v = (r == rm) ? st.Hl[r] : v;
-            a.score[pA] = (int)(int16_t)(v >> 16); a.endRow[pA] = m; a.endCol[pA] = n;
-            a.score[pB] = (int)(int16_t)(v & 0xFFFFu); a.endRow[pB] = m; a.endCol[pB] = n;
-        }
-    }
-}
-
-/* =====================================================================================================
  * Affine-gap (Gotoh) global fill: AffineNeedlemanWunsch (c++/AffineNeedlemanWunsch.cpp:167-240).
  *   D[i][j] = (i==1) ? H[i-1][j]+o+e : max(H[i-1][j]+o+e, D[i-1][j]+e)      vertical gap   (:185-197)
  *   I[i][j] = (j==1) ? H[i][j-1]+o+e : max(H[i][j-1]+o+e, I[i][j-1]+e)      horizontal gap (:201-213)
@@ -3324,21 +3113,6 @@ hipError_t dpx_launch_fill_split(const dpx_fill_args &a, int algo, int R, int wa
     default: return hipErrorInvalidValue; /* (8 rows per lane would spill under the 1024-thread launch bound) */
     }
 #undef DPX_SPLIT_CASE
-}
-
-/* packed split fill: a.order = couples (2 ints each), a.numPairs = number of couples, one workgroup of `waves` waves per couple */
-hipError_t dpx_launch_fill_split_packed(const dpx_fill_args &a, int algo, int R, int waves, size_t ldsBytes, hipStream_t stream) {
-    if (a.numPairs <= 0) return hipSuccess;
-    if (waves < 1 || waves > DPX_SPLIT_MAX_WAVES) return hipErrorInvalidValue;
-    const bool local = algo == DPX_K_LSW;
-    dim3 grid((unsigned)a.numPairs);
-    switch (R) {
-    case 2: return local ? launch_lanes_kernel(k_linear_split_pk<2, true>, a, grid, 64 * waves, ldsBytes, stream)
-                         : launch_lanes_kernel(k_linear_split_pk<2, false>, a, grid, 64 * waves, ldsBytes, stream);
-    case 4: return local ? launch_lanes_kernel(k_linear_split_pk<4, true>, a, grid, 64 * waves, ldsBytes, stream)
-                         : launch_lanes_kernel(k_linear_split_pk<4, false>, a, grid, 64 * waves, ldsBytes, stream);
-    default: return hipErrorInvalidValue;
-    }
 }
 
 /* packed two-pairs-per-wave linear fill: a.order = couples (2 ints each), a.numPairs = number of couples */

@@ -42,8 +42,8 @@ WEIGHTS = [(3, -1, -2, -1), (1, -1, -1, -1), (2, -3, 0, -1), (0, 0, 0, 0), (5, 2
 @pytest.mark.parametrize("seed", QUAD_SEEDS)
 @pytest.mark.parametrize("algo", ["LSW", "LNW", "ANW"])
 def test_fuzz_quad_kernels(gpu, algo, seed, monkeypatch):
-    """The same fuzz through the four-pairs-per-wave kernels (queries <= 256 rows; DPX_QUAD=1 forces them on small batches)."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    """The same fuzz through the four-pairs-per-wave kernels (queries <= 256 rows; DPX_LANES=1 forces them on small batches)."""
+    monkeypatch.setenv("DPX_LANES", "1")
     test_fuzz(gpu, algo, seed, max_lens=(70, 140, 256))
 
 

@@ -13,7 +13,6 @@ CASES = [
      [(7, 100, 131), (5, 250, 77), (4, 500, 513), (3, 1024, 1000), (3, 1000, 1024), (2, 1, 1), (2, 1, 300), (2, 300, 1)]),
     ("rolling multi-stripe schedule", {"DPX_SPLIT": "0"}, [(2, 2100, 700), (2, 1100, 130), (1, 4096, 4096)]),
     ("split", {"DPX_SPLIT": "1"}, [(5, 600, 500), (3, 257, 129), (3, 1024, 1024), (2, 2000, 300)]),
-    ("packed split", {"DPX_SPLIT": "1", "DPX_SPLIT_PK": "1"}, [(6, 600, 500), (5, 1024, 1023)]),
     ("packed couples + an odd pair", {"DPX_PACKED": "1"}, [(7, 1024, 1024), (5, 513, 700), (9, 120, 131), (3, 300, 8)]),
     ("lane-packed", {"DPX_LANES": "1"}, [(41, 100, 131), (9, 512, 300), (7, 1024, 99), (33, 17, 9)]),
     ("lane-packed int32", {"DPX_LANES": "1", "DPX_LANES_PK": "0"}, [(41, 100, 131), (9, 512, 300), (7, 1024, 99)]),

@@ -1,4 +1,4 @@
-"""GPU parity of the quad kernel (four pairs per wave, one per 16-lane DPP row; DPX_QUAD=1 forces it on small batches):
+"""GPU parity of the quad kernel (four pairs per wave, one per 16-lane DPP row; DPX_LANES=1 forces it on small batches):
 short queries of up to 256 rows, ragged mixes inside one wave, pair counts that leave a wave partly empty, empty
 sequences beside it on the one-pair-per-wave kernel.  Same checks as every path: every cell, end cell, printed lines."""
 import gzip
@@ -58,7 +58,7 @@ def _check(dpx, algo, sb, w, every=1, flags=0):
 @pytest.mark.parametrize("algo", ALGOS)
 def test_quad_uniform_shapes(gpu, algo, monkeypatch):
     """8 rows per lane up to 128 query rows, 16 (two sub-tiles) up to 256; 5 or 7 pairs leave the last wave partly empty."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     for i, (m, n) in enumerate([(1, 1), (5, 40), (8, 9), (100, 150), (128, 128), (129, 100), (256, 300), (250, 17), (17, 250)]):
         _check(gpu, algo, make_batch(5 + 2 * (i & 1), m, n, seed=700 + i, first_index=96), W3[algo])
 
@@ -67,7 +67,7 @@ def test_quad_uniform_shapes(gpu, algo, monkeypatch):
 def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, lanes_kernel, monkeypatch):
     """Lane-packed kernels at their limits: 8 rows per lane up to 512 query rows (64 lanes), 16 rows per lane (two row blocks
     per lane, linear-gap kernels only) up to 1024; mixes where a wave holds one long and several short pairs."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     shapes = [(512, 300), (505, 77), (300, 520)] + ([(513, 200), (1024, 1024), (700, 90), (1000, 7)] if algo != "ANW" else [])
     for i, (m, n) in enumerate(shapes):
         sb = make_batch(3, m, n, seed=900 + i, first_index=95)
@@ -84,7 +84,7 @@ def test_lanes_up_to_a_whole_wave_per_pair(gpu, algo, lanes_kernel, monkeypatch)
 @pytest.mark.parametrize("algo", ALGOS)
 def test_quad_ragged_and_empty(gpu, algo, monkeypatch):
     """Waves whose four pairs differ in both lengths; empty sequences are split off to the one-pair-per-wave kernel."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     _check(gpu, algo, make_ragged_batch(203, 30, 128, 20, 200, seed=31), W3[algo], every=3)
     _check(gpu, algo, make_ragged_batch(61, 100, 256, 90, 310, seed=32), W5[algo], every=2)
     _check(gpu, algo, from_strings([("", "01"), ("0123", "0123"), ("0123", "3210"), ("01", ""), ("3333", "3333"), ("", ""),
@@ -93,14 +93,14 @@ def test_quad_ragged_and_empty(gpu, algo, monkeypatch):
 
 @pytest.mark.parametrize("algo", ALGOS)
 def test_quad_score_only(gpu, algo, monkeypatch):
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     _check(gpu, algo, make_ragged_batch(150, 60, 140, 80, 170, seed=33), W3[algo], flags=gpu.SCORE_ONLY)
 
 
 @pytest.mark.parametrize("algo", ALGOS)
 def test_quad_reference_stdout_short400(gpu, algo, monkeypatch):
     """The reference's own stdout for 400 short-read pairs (tests/golden), through the quad kernel."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     sb = parse_pairs_file(os.path.join(G, "short400.txt"))
     want = gzip.open(os.path.join(G, f"short400_{algo}.out.gz"), "rb").read().decode("latin-1")
     with gpu.Batch({"LNW": 0, "LSW": 1, "ANW": 2}[algo], sb.sequences, sb.pairs, *W3[algo]) as b:
@@ -147,7 +147,7 @@ def test_packed_row_block_kernel_choice_and_edges(gpu, lanes_kernel, monkeypatch
     """k_linear_lanes_pk is chosen for LSW / LNW batches whose weights it can take, never for the others; shapes around its edges:
     queries of 1..17 rows (the low block empty or one row), references shorter than a lane group's skew, n a multiple of 8 and
     not, ties between rows of the two blocks of one lane."""
-    monkeypatch.setenv("DPX_QUAD", "1")
+    monkeypatch.setenv("DPX_LANES", "1")
     want = "k_linear_lanes_pk" if lanes_kernel == "packed-row-blocks" else "k_linear_lanes"
     sb = make_ragged_batch(60, 1, 40, 1, 60, seed=77)
     for algo, w, kern in (("LSW", (3, -1, -2, -1), want), ("LNW", (3, -1, -2, -1), want), ("LSW", (3, 5, 4, -1), "k_linear_lanes"),

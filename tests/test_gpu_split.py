@@ -9,14 +9,6 @@ from dpx_gpu_genomics_project_amd.synth import from_strings, make_batch, make_ra
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["packed-couples", "int32-only"])
-def split_kernel(request, monkeypatch):
-    """Round 3: equal-shaped pairs of a split batch run two per workgroup on the packed-int16 pipe (k_linear_split_pk), leftovers
-    and batches whose weights the 16-bit pipe cannot take on the int32 kernel (k_linear_split).  DPX_SPLIT_PK=0: int32 only."""
-    monkeypatch.setenv("DPX_SPLIT_PK", "0" if request.param == "int32-only" else "1")  # (the packed kernel is opt-in: it loses at ~1 wave per SIMD)
-    return request.param
-
-
 def _check(dpx, algo, sb, w, every=1, expect_split=True):
     code = {"LNW": dpx.ALGO_LNW, "LSW": dpx.ALGO_LSW}[algo]
     with dpx.Batch(code, sb.sequences, sb.pairs, *w) as b:
@@ -69,23 +61,20 @@ def test_split_is_the_default_for_small_batches_only(gpu, monkeypatch):
     _check(gpu, "LNW", make_batch(4, 600, 300, seed=3), (3, -1, -2), expect_split=False)
 
 
-def test_packed_split_couples_partial_stripes_and_refusals(gpu, split_kernel):
-    """k_linear_split_pk: all-couple batches, stripes that end inside their 64 * R rows (row masks of the start-cell keys), ties
-    between rows of one lane, and the weights it must leave to the int32 kernel."""
-    want_pk = split_kernel == "packed-couples"
+def test_split_partial_stripes_ties_and_weights(gpu):
+    """Stripes that end inside their 64 * R rows, ties between rows of one lane, weights of every sign (round 3 ran these on a packed
+    variant of the kernel as well -- deleted in round 4: it lost on every batch the split kernel fills)."""
     for i, (m, n) in enumerate([(512, 512), (300, 200), (130, 64), (515, 333), (1023, 90), (257, 700)]):
         d = _check(gpu, "LSW", make_batch(6, m, n, seed=1300 + i, first_index=96), (3, -1, -2))
-        assert (d["kernel"] == "k_linear_split_pk") == want_pk and d["couples"] == (3 if want_pk else 0), d
-        d = _check(gpu, "LNW", make_batch(4, m, n, seed=1400 + i, first_index=99), (3, -1, -2))
-        assert (d["kernel"] == "k_linear_split_pk") == want_pk, d
-    # many equal scores: first strict maximum must be the smallest row, then the smallest column (row tags inside a lane)
+        assert d["kernel"] == "k_linear_split" and d["couples"] == 0, d
+        _check(gpu, "LNW", make_batch(4, m, n, seed=1400 + i, first_index=99), (3, -1, -2))
+    # many equal scores: first strict maximum must be the smallest row, then the smallest column
     same = [(b"0" * 300, b"0" * 260), (b"01" * 150, b"01" * 130), (b"0" * 300, b"1" * 260), (b"0123" * 75, b"3210" * 65)]
     _check(gpu, "LSW", from_strings(same), (3, -1, -2))
     _check(gpu, "LSW", from_strings(same), (1, 0, 0))
     # positive gap / mismatch above match: rows past the query's end would collect score if they were not masked
     _check(gpu, "LSW", make_batch(4, 515, 200, seed=77), (3, 5, 4))
     _check(gpu, "LSW", make_batch(4, 130, 300, seed=78), (2, 3, 1))
-    # SW scores whose row tag would not fit 16 bits (score * R + R-1 > 65535), and adds that would wrap in 16 bits: int32 kernel
     big = make_batch(4, 600, 600, seed=5)
     for algo, w in (("LSW", (40, -1, -2)), ("LSW", (3, -40000, -2)), ("LNW", (3, -40000, -2))):
         d = _check(gpu, algo, big, w, every=2)

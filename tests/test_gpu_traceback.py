@@ -89,7 +89,7 @@ def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
                              ("0" * 300, "1" * 200 + "0" * 90), ("01" * 150, "10" * 40)])]   # long gaps: the walk leaves windows sideways
     for r, quad in (("8", "0"), ("8", "1"), ("16", "0")):
         monkeypatch.setenv("DPX_R", r)
-        monkeypatch.setenv("DPX_QUAD", quad)
+        monkeypatch.setenv("DPX_LANES", quad)
         extra = [make_batch(3, 64 * int(r) + 37, 200, seed=55, first_index=99)] if quad == "0" else [make_batch(9, 120, 140, seed=56), make_batch(5, 250, 90, seed=57)]
         for sb in (batches if quad == "0" else []) + extra:
             with gpu.Batch(CODE[algo], sb.sequences, sb.pairs, *w) as b:

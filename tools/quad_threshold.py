@@ -1,4 +1,4 @@
-"""Where does four-pairs-per-wave start to beat one-pair-per-wave on short reads?  (development aid; DPX_QUAD=0/1 per run)"""
+"""Where does four-pairs-per-wave start to beat one-pair-per-wave on short reads?  (development aid; DPX_LANES=0/1 per run)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpx_gpu_genomics_project_amd as dpx
@@ -10,7 +10,7 @@ for N in (1024, 2048, 4096, 8192, 16384):
     for algo in (dpx.ALGO_LNW, dpx.ALGO_ANW):
         for flags in (0, 1):
             for quad in ("0", "1"):
-                os.environ["DPX_QUAD"] = quad
+                os.environ["DPX_LANES"] = quad
                 b = dpx.Batch(algo, sb.sequences, sb.pairs, 3, -1, -3 if algo == dpx.ALGO_ANW else -2, -1, flags=flags)
                 b.fill_timed(2)
                 us = min(b.fill_timed(5) for _ in range(3))
