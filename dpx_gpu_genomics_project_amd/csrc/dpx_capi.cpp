@@ -1441,7 +1441,8 @@ static int create_impl(int device, const dpx_params *params, const char *sequenc
         }
         if (!known) rec = fresh_pool_record(pool, b->matPoolBytes);
         b->tunePool = tune && rec.candidatesMs.empty() && b->matPoolBytes >= ((size_t)1 << 30) && !b->guardBytes; /* (the memset probe would wipe the band) */
-        b->tuneShop = b->tunePool && fresh && probeEnv != 1; /* DPX_POOL_PROBE=1: time only, no shopping */
+        /* (shopping for a pool nobody has shopped for yet: a fresh one, or one that dpx_pool_reserve built ahead of time) */
+        b->tuneShop = b->tunePool && (fresh || rec.fillMs.empty()) && probeEnv != 1; /* DPX_POOL_PROBE=1: time only, no shopping */
         if (b->tunePool) rec.candidatesMs.assign(1, time_memset(pool, b->matPoolBytes, b->stream));
         b->dMat = (int16_t *)pool;
         b->poolRec = rec;

@@ -8,7 +8,7 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-device 0] [-noprint] [-pack2] [-producer P] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-tune 0|1] [-device 0] [-noprint] [-pack2] [-producer P] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
@@ -67,6 +67,7 @@ int main(int argc, char *argv[]) {
     bool print = true, pack2 = false;
     int producerFlag = -1; // producer threads; -1: by batch size (2 for batches of many short pairs, none for few long ones)
     int inflight = 2;      // batches on the device at a time (= matrix pools reserved)
+    int tuneFlag = -1;     // -1: by the length of the job
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -87,6 +88,7 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-pack2")) pack2 = true;
         else if (!strcmp(argv[i], "-producer")) producerFlag = atoi(next("-producer"));
         else if (!strcmp(argv[i], "-inflight")) inflight = atoi(next("-inflight"));
+        else if (!strcmp(argv[i], "-tune")) tuneFlag = atoi(next("-tune"));
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
@@ -194,16 +196,24 @@ int main(int argc, char *argv[]) {
     // ms (more than the overlap of one batch's traceback with the next batch's fill can ever win back), so batches with pools of
     // 16 GiB or more (an explicit -batch) run one after the other and share ONE parked pool; the printer thread still overlaps.
     size_t maxAlive = (size_t)inflight;
+    // Pool placement: the same fill runs up to 27 % apart on two allocations of one pool (ANW 1000 x 1024^2: 0.94 vs 1.20 ms;
+    // no address pattern of the fill moves it, profiles/r04/anw_group_sweep_on_fixed_allocations.txt).  A job of 256 batches or more lets the engine shop
+    // for its pools with the first batch that uses each of them (DPX_TUNE_PLACEMENT: five candidate allocations, four fills each -- ~35 ms per pool,
+    // once); shorter jobs would not earn that back.  -tune 0|1 overrides.
+    const size_t jobBatches = (shardHi - shardLo + batchSize - 1) / batchSize;
+    const bool tunePools = tuneFlag >= 0 ? tuneFlag != 0 : jobBatches >= 256;
+    std::atomic<int> tuned{0}; // batches created with the flag so far (one per pool in flight)
     std::atomic<uint64_t> create_time{0}; // summed over the threads that produce
     auto produce = [&](size_t first) -> InFlight {
         InFlight next;
         next.first = first;
         next.count = std::min(batchSize, shardHi - first);
         const uint64_t t0 = get_time();
+        const unsigned flags = DPX_KEEP_MATRICES | DPX_TIME_FILLS | ((tunePools && tuned.fetch_add(1) < inflight) ? DPX_TUNE_PLACEMENT : 0u);
         int prc = pack2 ? dpx_batch_create_packed2(-1, &prm, packed.data(), fileInfo.numBytes, alphabet, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs),
-                                                   first, next.count, DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b)
+                                                   first, next.count, flags, &next.b)
                         : dpx_batch_create(&prm, sequences, fileInfo.numBytes, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs), first, next.count,
-                                           DPX_KEEP_MATRICES | DPX_TIME_FILLS, &next.b);
+                                           flags, &next.b);
         if (prc != DPX_OK) die("FAILED TO CREATE DEVICE BATCH", prc);
         create_time += get_time() - t0;
         if ((prc = dpx_batch_fill(next.b, nullptr)) != DPX_OK) die("KERNEL LAUNCH FAILED", prc);

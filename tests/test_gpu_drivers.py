@@ -115,6 +115,23 @@ def test_batches_from_the_pool_budget_print_the_same_text(tmp_path):
                 assert f"\n{p} | {O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, want_dir=False).score}\n" in "\n" + one
 
 
+def test_pipeline_depth_producer_threads_and_tuned_pools_print_the_same_text(tmp_path):
+    """Round 4: -inflight K batches on the device at a time, -producer P threads creating them (finished in input order), -tune 1 (the
+    first batch on every pool shops for its placement: DPX_TUNE_PLACEMENT on pools of >= 1 GiB that dpx_pool_reserve built ahead of time)."""
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    from dpx_gpu_genomics_project_amd.synth import make_batch
+    sb = make_batch(1300, 1024, 1024, seed=33, first_index=95)     # 1-GiB budget: ~430 pairs per batch, 4 batches
+    path = str(tmp_path / "p1300.txt")
+    write_pairs_file(sb, path)
+    body = lambda out: out[out.index("Pair # | Score\n") + 15:out.index("Elapsed time (usec): ")]
+    base = [os.path.join(HOST, "dpx_main"), "-pairs", path] + W["LSW"] + ["-algo", "LSW", "-pool-gb", "1"]
+    want = body(run(base))
+    for extra in (["-inflight", "3"], ["-inflight", "1"], ["-producer", "2"], ["-producer", "3", "-inflight", "2"], ["-tune", "1"], ["-tune", "1", "-producer", "2"]):
+        assert body(run(base + extra)) == want, extra
+    for p in (0, 431, 1299):
+        assert f"\n{p} | {O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, want_dir=False).score}\n" in "\n" + want
+
+
 def test_tail_pairs_are_not_dropped(tmp_path):
     """The reference main drops pairs past the last full 400 (c++/main.cpp:169); the mirror's drivers must not."""
     subprocess.run(["make", "-s", "-C", HOST], check=True)
