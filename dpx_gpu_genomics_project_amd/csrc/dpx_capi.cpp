@@ -1755,13 +1755,13 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         /* How to walk (round 4, tools/tb_kernel.sh, kernel time alone; profiles/r04/traceback_walks.txt).  Walk 2 = one WAVE per pair
          * (k_traceback_wave: runs of path steps decided by all lanes at once from an LDS window): LSW / LNW always -- 1000 x 512^2 0.13 vs
          * 0.60 ms for one lane per pair, 16 000 x 512^2 0.50 vs 0.76, 20 000 x 300^2 0.36 vs 0.54, 100 000 short reads 0.33 vs 0.57 (LSW) /
-         * 0.71 vs 0.69 (LNW); ANW (three planes per window) up to 6000 pairs, or up to 20 000 pairs of long paths -- 1000 x 512^2 0.21 vs
-         * 1.16, 5000 x 1024^2 1.68 vs 2.51, but 20 000 x 300^2 1.75 vs 0.98 and 100 000 short reads 1.61 vs 0.98.  Walks 0 / 1 = one lane
+         * 0.71 vs 0.69 (LNW); ANW (three planes per window, 48-row banded windows) up to 20 000 pairs -- 1000 x 512^2 0.17 vs 1.16,
+         * 5000 x 1024^2 0.86 vs 2.51, 20 000 x 300^2 0.92 vs 0.98, but 100 000 short reads 1.48 vs 0.98.  Walks 0 / 1 = one lane
          * per pair, cell by cell / through register-cached column vectors (the latter from 64k pairs on: enough lanes in flight to thrash
          * L1 / L2 between two steps of a lane).  Banded matrices: one lane per pair.  DPX_TB_WALK=0/1/2 forces one (tests). */
         int walk = b->numPairs >= 65536 ? 1 : 0;
         if (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW) walk = 2;
-        else if (b->kernelAlgo == DPX_ALGO_ANW && (b->numPairs < 6000 || (b->maxM + b->maxN >= 1500 && b->numPairs < 20000))) walk = 2;
+        else if (b->kernelAlgo == DPX_ALGO_ANW && b->numPairs <= 20000) walk = 2;
         { const int w = knobs().tbWalk; if (w >= 0) walk = std::min(2, w); }
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));
         b->tbLinesValid = true;

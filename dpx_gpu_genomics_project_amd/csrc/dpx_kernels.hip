@@ -2483,7 +2483,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
 /* -----------------------------------------------------------------------------------------------------
  * Wave-cooperative traceback (LSW / LNW / ANW, every matrix layout of the fill kernels).
  * The lane-per-pair walk above pays one dependent HBM round trip per path step (1100 of them on a 1024 x 1024 pair).  Here
- * one WAVE owns a pair: lane c fetches column cLo + c of a window of the matrix around the walker -- 64 rows (ANW: 32 rows of
+ * one WAVE owns a pair: lane c fetches column cLo + c of a window of the matrix around the walker -- 64 rows (ANW: 48 rows of
  * every plane) x 64 columns, the 8 rows of a row group with one 16-byte load (layouts with fewer than 8 rows per lane: 8- or
  * 4-byte pieces) -- into LDS (one 144-byte line per column and plane, borders included as ordinary cells), and the walk runs
  * until it leaves the window through its top or its left edge: one HBM round trip per ~64 steps of a diagonal path.
@@ -2499,7 +2499,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
  * are mostly long diagonal runs: a 1024 x 1024 pair of the benchmark is ~90 trips instead of ~2050.
  * ----------------------------------------------------------------------------------------------------- */
 template <int PLANES> struct TbWin {
-    static constexpr int G = PLANES == 3 ? 4 : 8;      /* row groups of a window */
+    static constexpr int G = PLANES == 3 ? 6 : 8;      /* row groups of a window */
     static constexpr int WR = 8 * G;                   /* rows R0+1 .. R0+WR; columns cLo .. cLo+63, one per lane */
     static constexpr int CS = WR + 8;                  /* int16 elements between two columns in LDS: 16-byte aligned lines, banks spread */
     static constexpr int kBytes = PLANES * 64 * CS * 2;
@@ -2580,14 +2580,14 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
         const int jc = cLo + lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); /* the previous window's reads are done before it is overwritten (LDS only: the walk's byte stores are not waited for) */
         __builtin_amdgcn_wave_barrier();
-        /* One plane (LSW / LNW): only a BAND of the window is fetched -- the three row groups of every column around the diagonal through the
+        /* Only a BAND of the window is fetched -- the three row groups of every column (and plane) around the diagonal through the
          * anchor (rows d-8 .. d+7 at least, d = the diagonal's row in that column).  The walk follows that diagonal or leaves it by a few
          * gap steps; need_window() re-anchors when it is more than 7 rows above / 6 below.  In the wavefront-tiled layouts every column's
          * piece lies in its own 64-byte sector, so 3 instead of 8 pieces per column are 3/8 of the traffic and of the requests (the
          * traceback of 10 000 pairs of 1024 x 1024 read ~5 GB for paths that touch ~0.3 GB). */
-        constexpr int GL = PLANES == 1 ? 3 : G; /* row groups of a banded column */
+        constexpr int GL = 3; /* row groups of a banded column */
         diag0 = ii - jj;
-        banded = PLANES == 1 && !wantFull;
+        banded = !wantFull;
         const int dl = (ii - R0 - 1) - 63 + lane;
         const int gFirst = banded ? min(max((dl - 8) >> 3, 0), G - GL) : 0;
         const int gCount = banded ? GL : G;
@@ -2751,9 +2751,9 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
                 /* INSERTION: steps to the left along row r until (and including) the cell where the gap was opened; lane l decides the cell in column l */
                 const int cq = max(lane, 1), jc = cLo + cq;
                 const bool opened = jc == 1 || cell(0, cq - 1, r) + g + ext >= cell(1, cq - 1, r) + ext;
-                const bool usable = lane <= c && lane >= 1 && jc >= 1;
+                const bool usable = lane <= c && lane >= 1 && jc >= 1 && (!banded || (i - j) - diag0 + (c - lane) <= 6); /* (column l-1, row r inside the band) */
                 const int cont = run_down(usable && !opened, c);          /* cells the gap passes through */
-                const bool stops = c - cont >= 1 && cLo + c - cont >= 1;  /* ... and then a usable cell that opened it (else: the window's edge) */
+                const bool stops = c - cont >= 1 && cLo + c - cont >= 1 && (!banded || (i - j) - diag0 + cont <= 6); /* ... and then a usable cell that opened it (else: the window's / band's edge) */
                 const int len = cont + (stops ? 1 : 0);
                 emit_left(c, len); j -= len;
                 if (stops) cur = 0;
@@ -2761,10 +2761,10 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
                 /* DELETION: steps up along column c; lane k decides the cell k rows above the walker */
                 const int rq = max(r - lane, 1), ii = R0 + 1 + rq;
                 const bool opened = ii == 1 || cell(0, c, rq - 1) + g + ext >= cell(2, c, rq - 1) + ext;
-                const bool usable = r - lane >= 1 && ii >= 1;
+                const bool usable = r - lane >= 1 && ii >= 1 && (!banded || (i - j) - diag0 - lane >= -7); /* (column c, row r-k-1 inside the band) */
                 const unsigned long long m64 = __builtin_amdgcn_ballot_w64(!(usable && !opened)); /* first lane that ends the run: opened, or not usable */
                 const int cont = m64 ? __builtin_ctzll(m64) : 64;
-                const bool stops = r - cont >= 1 && R0 + 1 + r - cont >= 1;
+                const bool stops = r - cont >= 1 && R0 + 1 + r - cont >= 1 && (!banded || (i - j) - diag0 - cont >= -7);
                 const int len = cont + (stops ? 1 : 0);
                 emit_up(r, len); i -= len;
                 if (stops) cur = 0;
