@@ -8,7 +8,7 @@
 // stdout keeps the reference's lines so logs stay diff-able.
 //
 //   dpx_main -pairs <file> [-match 3] [-mismatch -1] [-open -2 | -gap -2] [-extend -1]
-//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-tune 0|1] [-ramp 0|1] [-device 0] [-noprint] [-pack2] [-producer P] [-rank r -world w]
+//            [-algo LSW|LNW|ANW|BSW] [-band 128] [-batch N | -pool-gb 4] [-inflight K] [-tune 0|1] [-device 0] [-noprint] [-pack2] [-producer P] [-rank r -world w]
 //
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
@@ -68,7 +68,6 @@ int main(int argc, char *argv[]) {
     int producerFlag = -1; // producer threads; -1: by batch size (2 for batches of many short pairs, none for few long ones)
     int inflight = 2;      // batches on the device at a time (= matrix pools reserved)
     int tuneFlag = -1;     // -1: by the length of the job
-    int rampFlag = -1;     // -1: ramped batch sizes when the batch size comes from the pool budget
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
         auto next = [&](const char *flag) -> const char * {
@@ -90,7 +89,6 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(argv[i], "-producer")) producerFlag = atoi(next("-producer"));
         else if (!strcmp(argv[i], "-inflight")) inflight = atoi(next("-inflight"));
         else if (!strcmp(argv[i], "-tune")) tuneFlag = atoi(next("-tune"));
-        else if (!strcmp(argv[i], "-ramp")) rampFlag = atoi(next("-ramp"));
         else if (!strcmp(argv[i], "-rank")) rank = atoi(next("-rank"));
         else if (!strcmp(argv[i], "-world")) world = atoi(next("-world"));
         else { fprintf(stderr, "unknown argument: %s\n", argv[i]); exit(EXIT_FAILURE); }
@@ -135,7 +133,6 @@ int main(int argc, char *argv[]) {
     const size_t shardLo = 0, shardHi = fileInfo.numPairs; // indices into this rank's own records
     if (world > 1) printf("Rank %d of %d: pairs [%zu, %zu)\n\n", rank, world, shardFirst, shardFirst + fileInfo.numPairs);
 
-    const bool sizedFromBudget = batchSize == 0;
     if (batchSize == 0) { // pairs per batch from the pool budget: 2 bytes per cell and plane, rows / columns padded as the layouts pad them
         const double cols = (algo == DPX_ALGO_BSW && 2.0 * band < (double)fileInfo.maxReferenceLength) ? 2.0 * band + 8 : (double)fileInfo.maxReferenceLength + 128;
         const double perPair = 2.0 * (algo == DPX_ALGO_ANW ? 3 : 1) * ((double)fileInfo.maxQueryLength + 64) * cols;
@@ -203,36 +200,14 @@ int main(int argc, char *argv[]) {
     // no address pattern of the fill moves it, profiles/r04/anw_group_sweep_on_fixed_allocations.txt).  A job of 256 batches or more lets the engine shop
     // for its pools with the first batch that uses each of them (DPX_TUNE_PLACEMENT: five candidate allocations, four fills each -- ~35 ms per pool,
     // once); shorter jobs would not earn that back.  -tune 0|1 overrides.
-    // The batches.  With sizes from the pool budget the first two and the last two are a quarter and a half of a batch (-ramp 0|1): the pipeline is
-    // a chain create -> fill -> traceback -> text -> D2H -> print per batch, so the first batch's fill starts after a quarter of a create, and behind the
-    // last fill only a quarter of a batch is traced back, copied and printed (profiles/r04/e2e_ramped_batches.txt).
-    const bool ramped = (rampFlag >= 0 ? rampFlag != 0 : sizedFromBudget) && shardHi - shardLo >= 3 * batchSize && batchSize >= 64;
-    std::vector<std::pair<size_t, size_t>> batches; // (first pair, count)
-    {
-        auto even = [](size_t v) { return std::max<size_t>(2, v & ~(size_t)1); };
-        const size_t total = shardHi - shardLo;
-        std::vector<size_t> sizes;
-        if (ramped) {
-            const size_t q = even(batchSize / 4), h = even(batchSize / 2);
-            const size_t middle = total - 2 * q - 2 * h;
-            const size_t nMid = (middle + batchSize - 1) / batchSize;
-            sizes.push_back(q); sizes.push_back(h);
-            for (size_t k = 0, left = middle; k < nMid; k++) { const size_t c = k + 1 < nMid ? even((left + (nMid - k) - 1) / (nMid - k)) : left; sizes.push_back(c); left -= c; }
-            sizes.push_back(h); sizes.push_back(q);
-        } else {
-            for (size_t left = total; left;) { const size_t c = std::min(batchSize, left); sizes.push_back(c); left -= c; }
-        }
-        size_t first = shardLo;
-        for (size_t c : sizes) { if (c) batches.emplace_back(first, c); first += c; }
-    }
-    const size_t jobBatches = batches.size();
+    const size_t jobBatches = (shardHi - shardLo + batchSize - 1) / batchSize;
     const bool tunePools = tuneFlag >= 0 ? tuneFlag != 0 : jobBatches >= 256;
     std::atomic<int> tuned{0}; // batches created with the flag so far (one per pool in flight)
     std::atomic<uint64_t> create_time{0}; // summed over the threads that produce
-    auto produce = [&](size_t first, size_t count) -> InFlight {
+    auto produce = [&](size_t first) -> InFlight {
         InFlight next;
         next.first = first;
-        next.count = count;
+        next.count = std::min(batchSize, shardHi - first);
         const uint64_t t0 = get_time();
         const unsigned flags = DPX_KEEP_MATRICES | DPX_TIME_FILLS | ((tunePools && tuned.fetch_add(1) < inflight) ? DPX_TUNE_PLACEMENT : 0u);
         int prc = pack2 ? dpx_batch_create_packed2(-1, &prm, packed.data(), fileInfo.numBytes, alphabet, reinterpret_cast<const dpx_seq_pair *>(sequenceIdxs),
@@ -256,7 +231,7 @@ int main(int argc, char *argv[]) {
     // issuing thread is as fast or faster (10000 x 1024^2: 8.1-8.9 vs 8.4-9.3 ms).  -producer 0 turns the threads off.
     const int producers = producerFlag >= 0 ? std::min(producerFlag, 8) : (batchSize >= 8192 ? 2 : 0);
     if (producers > 0) {
-        const size_t numBatches = batches.size();
+        const size_t numBatches = (shardHi - shardLo + batchSize - 1) / batchSize;
         if ((size_t)producers + 1 > maxAlive) maxAlive = std::min<size_t>(8, (size_t)producers + 1); // (every producer needs a slot of its own)
         std::mutex qm;
         std::condition_variable qcv;
@@ -274,7 +249,7 @@ int main(int argc, char *argv[]) {
                         std::unique_lock<std::mutex> lk(qm);
                         qcv.wait(lk, [&]() { return k < consumed + maxAlive; });
                     }
-                    const InFlight next = produce(batches[k].first, batches[k].second);
+                    const InFlight next = produce(shardLo + k * batchSize);
                     std::lock_guard<std::mutex> lk(qm);
                     if (pool_is_huge(next)) maxAlive = 1;
                     ready[k] = next;
@@ -296,9 +271,9 @@ int main(int argc, char *argv[]) {
         for (std::thread &t : pool) t.join();
     } else {
         std::deque<InFlight> alive; // issued to the device, oldest first
-        for (const auto &bt : batches) {
+        for (size_t first = shardLo; first < shardHi; first += batchSize) {
             if (alive.size() >= maxAlive) { finish(alive.front()); alive.pop_front(); } // (its pool is parked for the batch produced next)
-            alive.push_back(produce(bt.first, bt.second));
+            alive.push_back(produce(first));
             if (pool_is_huge(alive.back())) maxAlive = 1;
         }
         while (!alive.empty()) { finish(alive.front()); alive.pop_front(); }
