@@ -1758,9 +1758,10 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
          * 0.71 vs 0.69 (LNW); ANW (three planes per window, 48-row banded windows) up to 20 000 pairs -- 1000 x 512^2 0.17 vs 1.16,
          * 5000 x 1024^2 0.86 vs 2.51, 20 000 x 300^2 0.92 vs 0.98, but 100 000 short reads 1.48 vs 0.98.  Walks 0 / 1 = one lane
          * per pair, cell by cell / through register-cached column vectors (the latter from 64k pairs on: enough lanes in flight to thrash
-         * L1 / L2 between two steps of a lane).  Banded matrices: one lane per pair.  DPX_TB_WALK=0/1/2 forces one (tests). */
+         * L1 / L2 between two steps of a lane).  Banded matrices: walk 2 as well (its band-layout window loads; numbers in the same file).
+         * DPX_TB_WALK=0/1/2 forces one (tests). */
         int walk = b->numPairs >= 65536 ? 1 : 0;
-        if (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW) walk = 2;
+        if (b->kernelAlgo == DPX_ALGO_LSW || b->kernelAlgo == DPX_ALGO_LNW || b->kernelAlgo == DPX_ALGO_BSW) walk = 2;
         else if (b->kernelAlgo == DPX_ALGO_ANW && b->numPairs <= 20000) walk = 2;
         { const int w = knobs().tbWalk; if (w >= 0) walk = std::min(2, w); }
         HIP_TRY(dpx_launch_traceback(b->args, (int)np, b->kernelAlgo, b->R, b->planes, walk, b->dTbOff, b->dTb, b->dTbLen, b->stream));

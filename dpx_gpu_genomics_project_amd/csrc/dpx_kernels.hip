@@ -2481,7 +2481,7 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
 }
 
 /* -----------------------------------------------------------------------------------------------------
- * Wave-cooperative traceback (LSW / LNW / ANW, every matrix layout of the fill kernels).
+ * Wave-cooperative traceback (LSW / LNW / ANW / banded SW, every matrix layout of the fill kernels).
  * The lane-per-pair walk above pays one dependent HBM round trip per path step (1100 of them on a 1024 x 1024 pair).  Here
  * one WAVE owns a pair: lane c fetches column cLo + c of a window of the matrix around the walker -- 64 rows (ANW: 48 rows of
  * every plane) x 64 columns, the 8 rows of a row group with one 16-byte load (layouts with fewer than 8 rows per lane: 8- or
@@ -2496,7 +2496,16 @@ __global__ void k_traceback(const dpx_fill_args a, int numPairs, int algo, int R
  * line: the length of the run of "diagonal" decisions below the walker's lane (LSW: up / left / diagonal / stop at H = 0; LNW:
  * INSERTION over DELETION over diagonal, borders included; ANW: the SCORING state's choice, "the gap was opened here" for the two
  * gap states, c++/backtrack.cpp:214-356).  The lanes of the run store their own three characters.  Alignments worth computing
- * are mostly long diagonal runs: a 1024 x 1024 pair of the benchmark is ~90 trips instead of ~2050.
+ * are mostly long diagonal runs: a 1024 x 1024 pair of the benchmark is ~90 trips instead of ~2050 -- ~50 since a trip also takes the
+ * step that ENDS its run (the lane below the run has decided that cell in the same pass: a diagonal run and the single gap step
+ * after it are one trip).  Measured per wave (s_memrealtime around the phases, 1024 x 1024 LSW): 19 windows of ~1.3 us load latency
+ * on an idle chip (4 us with 1700 waves loading at once: ~200 distinct lines per wave and window against the CUs' miss queues) and
+ * ~50 trips of 0.43 us; the batch's kernel time is its SLOWEST pair -- the benchmark's 1 % unrelated pairs, whose alignments under
+ * +3 / -1 / -2 are 300 short runs: 0.19-0.25 ms against 0.06-0.13 for the others.  A prefetch of the next window along the diagonal
+ * was built and measured (19 of 21 windows adopted): no gain with 1700 waves in flight (the loads are queued, not late), removed.
+ * Banded SW (round 4, BAND): the same walk with LSW's rule; the window is gathered from the anti-diagonal-major band layout with
+ * 2-byte loads (issue<3, .>), cells outside the band are 0.  4000 pairs of 4096 x 4096, band 128: 1.7 ms per batch of 1712 against
+ * 10 ms for one lane per pair.
  * ----------------------------------------------------------------------------------------------------- */
 template <int PLANES> struct TbWin {
     static constexpr int G = PLANES == 3 ? 6 : 8;      /* row groups of a window */
@@ -2525,10 +2534,13 @@ __device__ __forceinline__ u32x4 tb_load_group8(const int16_t *base, const dpx_p
     return v;
 }
 
-template <int PLANES>
-__global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int algo, int R, const int32_t *endRow,
+template <int PLANES, bool BAND, int ALGO>
+__global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, int numPairs, int R, const int32_t *endRow,
                                                        const int32_t *endCol, const uint64_t *tbOff, char *tb, int32_t *tbLen) {
     using W = TbWin<PLANES>;
+    /* BAND: a banded SW matrix (anti-diagonal-major band layout, dpx_band_index) walked by LSW's rule; cells outside the band read 0
+     * (TbView::get, c++/BandedSmithWaterman.cpp's back-tracker sees the zero-initialised matrix there) */
+    constexpr int algo = BAND ? DPX_K_LSW : ALGO; /* (compile-time: the walk of one algorithm carries no branches for the others) */
     constexpr int G = W::G, WR = W::WR, CS = W::CS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemTb[];
     int16_t *win = reinterpret_cast<int16_t *>(smemTb); /* win[(plane * 64 + (jj - cLo)) * CS + (ii - R0 - 1)] = plane[ii][jj] */
@@ -2538,8 +2550,8 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     const dpx_pair_dev pr = a.pairs[p];
     const int n = pr.n, m = pr.m;
     const int Rr = pr.rows ? (int)pr.rows : R;
-    /* (the host launches this kernel for LSW / LNW with one plane and ANW with three, never for banded matrices; rows per lane are
-     * 2, 4, 8 or 16 in every layout; empty sequences walk along a border or not at all) */
+    /* (the host launches this kernel for LSW / LNW / banded SW with one plane and ANW with three; rows per lane are
+     * 2, 4, 8 or 16 in every full-matrix layout; empty sequences walk along a border or not at all) */
     const unsigned char *ref = reinterpret_cast<const unsigned char *>(a.seq + pr.refIdx);
     const unsigned char *qry = reinterpret_cast<const unsigned char *>(a.seq + pr.qryIdx);
     const int16_t *base = a.mat + pr.matOff;
@@ -2553,18 +2565,18 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     const int Q = Rr >> 3, lgQ = Q == 2 ? 1 : 0;
     const int kind = Rr >= 8 ? (pr.lanes == 64 ? 0 : pr.lanes == 16 ? 1 : 2) : 2;
     const uint32_t cs = pr.chunkStride; /* (tile layout: the pair's first lane) */
-    auto piece = [&](const int pl, const int grp, const int jc) -> u32x4 {
-        if (kind == 0) { /* wavefront-tiled (dpx_tiled_index + dpx_tile_off) */
+    const int swBand = a.band, bandSc = BAND ? dpx_log2(dpx_band_cpl(a.band)) : 0; /* banded SW: band width, log2(cells per lane) */
+    /* where the 16-byte piece (rows 8*grp+1 .. +8 of column jc, plane pl) lies, for the two layouts whose lanes own >= 8 rows */
+    auto piece_at = [&](auto kindC, const int pl, const int grp, const int jc) -> const int16_t * {
+        if constexpr (decltype(kindC)::value == 0) { /* wavefront-tiled (dpx_tiled_index + dpx_tile_off) */
             const int l = (grp >> lgQ) & 63, kk = grp >> (lgQ + 6), sub = grp & (Q - 1);
             const size_t T = (size_t)kk * (size_t)n + (size_t)(jc - 1) + (size_t)l;
-            return *reinterpret_cast<const u32x4 *>(base + T * cs + (size_t)(((((pl << lgQ) + sub) << 6) + l) << 3));
-        }
-        if (kind == 1) { /* tile layout of the lane-packed kernels (dpx_wtile_index) */
+            return base + T * cs + (size_t)(((((pl << lgQ) + sub) << 6) + l) << 3);
+        } else { /* tile layout of the lane-packed kernels (dpx_wtile_index) */
             const int l = grp >> lgQ, h = grp & (Q - 1), lam = (int)cs + l, skew = l + ((int)cs & 7), j0 = jc - 1;
             const size_t t = (size_t)(((j0 >> 3) + 1) * 8 + skew - 1);
-            return *reinterpret_cast<const u32x4 *>(base + t * (size_t)(PLANES * Q * 512) + (size_t)((((pl << lgQ) + h) << 9) + ((lam >> 3) << 6) + ((j0 & 7) << 3)));
+            return base + t * (size_t)(PLANES * Q * 512) + (size_t)((((pl << lgQ) + h) << 9) + ((lam >> 3) << 6) + ((j0 & 7) << 3));
         }
-        return tb_load_group8(base, pr, Rr, PLANES, pl, grp, jc, n);
     };
     int i = __builtin_amdgcn_readfirstlane(endRow[p]), j = __builtin_amdgcn_readfirstlane(endCol[p]);
     int R0 = 1 << 28, cLo = 1 << 28;
@@ -2573,47 +2585,105 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
     bool wantFull = false; /* the walk left the last band sideways (a long gap): fetch whole columns next time */
     uint32_t chR = 0u, chQ = 0u; /* reference character of this lane's column; query character of window row `lane` */
     /* window with (ii, jj) in its bottom-right corner region */
-    auto load_window = [&](const int ii, const int jj) {
-        const int gBase = ((ii - 1) >> 3) - (G - 1);
-        R0 = gBase * 8;
-        cLo = jj - 63;
-        const int jc = cLo + lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); /* the previous window's reads are done before it is overwritten (LDS only: the walk's byte stores are not waited for) */
-        __builtin_amdgcn_wave_barrier();
-        /* Only a BAND of the window is fetched -- the three row groups of every column (and plane) around the diagonal through the
-         * anchor (rows d-8 .. d+7 at least, d = the diagonal's row in that column).  The walk follows that diagonal or leaves it by a few
-         * gap steps; need_window() re-anchors when it is more than 7 rows above / 6 below.  In the wavefront-tiled layouts every column's
-         * piece lies in its own 64-byte sector, so 3 instead of 8 pieces per column are 3/8 of the traffic and of the requests (the
-         * traceback of 10 000 pairs of 1024 x 1024 read ~5 GB for paths that touch ~0.3 GB). */
-        constexpr int GL = 3; /* row groups of a banded column */
-        diag0 = ii - jj;
-        banded = !wantFull;
-        const int dl = (ii - R0 - 1) - 63 + lane;
-        const int gFirst = banded ? min(max((dl - 8) >> 3, 0), G - GL) : 0;
-        const int gCount = banded ? GL : G;
-        u32x4 v[PLANES][G];
+    /* Window with (ii, jj) in its bottom-right corner region.  Only a BAND of it is fetched unless the walk left the last one sideways
+     * -- the three row groups of every column (and plane) around the diagonal through the anchor (rows d-8 .. d+7 at least, d = the
+     * diagonal's row in that column).  The walk follows that diagonal or leaves it by a few gap steps; need_window() re-anchors when it
+     * is more than 7 rows above / 6 below.  In the wavefront-tiled layouts every column's piece lies in its own 64-byte sector, so 3
+     * instead of 8 pieces per column are 3/8 of the traffic and of the requests (the traceback of 10 000 pairs of 1024 x 1024 read
+     * ~5 GB for paths that touch ~0.3 GB).
+     * fill_window<KIND, CNT>: the loads of one layout (0 wavefront-tiled, 1 tile layout, 2 any layout through dpx_cell_index, 3 band
+     * layout) and one group count, straight-line -- round 4 found a window's loads spending ~3000 cycles in the nest of uniform
+     * branches that one loop over "whatever layout, however many groups" compiled to (a taken branch is a fetch bubble).  Cells
+     * without storage (rows past m, columns outside 1..n, outside the band) load the pool's first bytes instead of branching and are
+     * masked to 0 afterwards. */
+    constexpr int GL = 3; /* row groups of a banded column */
+    /* issue<KIND, CNT>: the loads of a window -- CNT row groups from group gBase + gFirst (per lane) of column jc, the query characters of
+     * rows r0 + 1 + lane and the reference character of the column -- into `raw`, nothing else: no value is touched, so every load of the window is
+     * in flight before the wave waits for the first. */
+    auto issue = [&](auto kindC, auto cntC, auto &raw, uint32_t &rawQ, uint32_t &rawR, const int gBase, const int gFirst, const int jc, const int r0) {
+        constexpr int KIND = decltype(kindC)::value, CNT = decltype(cntC)::value;
+        if constexpr (KIND == 3) {
+            /* Band layout (dpx_band_index, its shifts hoisted): the rows of a column lie on consecutive anti-diagonals -- 2-byte loads,
+             * 24 per lane in a banded window (neighbouring columns and rows share 64-byte sectors: ~60 distinct ones for the wave). */
+            const int sg = 3 - bandSc;
 #pragma unroll
-        for (int pl = 0; pl < PLANES; pl++) {
+            for (int gi = 0; gi < CNT; gi++) {
 #pragma unroll
-            for (int gi = 0; gi < G; gi++) { /* all loads in flight together */
-                const int grp = gBase + gFirst + gi;
-                v[pl][gi] = u32x4{0u, 0u, 0u, 0u};
-                if (gi < gCount && grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n) v[pl][gi] = piece(pl, grp, jc);
+                for (int e = 0; e < 8; e++) {
+                    const int ii2 = (gBase + gFirst + gi) * 8 + 1 + e, dlt = ii2 - jc, A = ii2 + jc - 2, sl = (dlt + swBand - 1) >> 1;
+                    const bool ok = ii2 >= 1 && ii2 <= m && jc >= 1 && jc <= n && dlt < swBand && -dlt < swBand;
+                    const size_t off = (size_t)(A >> sg) * cs + (size_t)(((sl >> bandSc) << 3) + ((A & ((1 << sg) - 1)) << bandSc) + (sl & ((1 << bandSc) - 1)));
+                    const int16_t *at = ok ? base + off : a.mat;
+                    raw[gi * 8 + e] = (uint32_t)*reinterpret_cast<const uint16_t *>(at);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < PLANES; pl++) {
+#pragma unroll
+                for (int gi = 0; gi < CNT; gi++) {
+                    const int grp = gBase + gFirst + gi;
+                    const bool ok = grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n;
+                    u32x4 x;
+                    if constexpr (KIND == 2) {
+                        x = u32x4{0u, 0u, 0u, 0u};
+                        if (ok) x = tb_load_group8(base, pr, Rr, PLANES, pl, grp, jc, n);
+                    } else {
+                        const int16_t *at = ok ? piece_at(kindC, pl, grp, jc) : a.mat;
+                        x = *reinterpret_cast<const u32x4 *>(at);
+                    }
+                    const int k = (pl * CNT + gi) * 4;
+                    raw[k] = x.x; raw[k + 1] = x.y; raw[k + 2] = x.z; raw[k + 3] = x.w;
+                }
             }
         }
-        { const int qi = R0 + lane; chQ = (lane < WR && qi >= 0 && qi < m) ? qry[qi] : 0u; } /* query character of row R0 + 1 + lane */
-        chR = (jc >= 1 && jc <= n) ? ref[jc - 1] : 0u;
+        const int qi = r0 + lane;
+        const unsigned char *atQ = (lane < WR && qi >= 0 && qi < m) ? qry + qi : reinterpret_cast<const unsigned char *>(a.seq);
+        const unsigned char *atR = (jc >= 1 && jc <= n) ? ref + (jc - 1) : reinterpret_cast<const unsigned char *>(a.seq);
+        rawQ = *atQ;
+        rawR = *atR;
+    };
+    /* commit<KIND, CNT>: what issue() loaded becomes the window in LDS -- cells without storage masked to 0, the borders of H added as
+     * ordinary cells -- and the lane's two characters */
+    auto commit = [&](auto kindC, auto cntC, const auto &raw, const uint32_t rawQ, const uint32_t rawR, const int gBase, const int gFirst, const int jc, const int r0) {
+        constexpr int KIND = decltype(kindC)::value, CNT = decltype(cntC)::value;
+        u32x4 v[PLANES][CNT];
+        if constexpr (KIND == 3) {
+#pragma unroll
+            for (int gi = 0; gi < CNT; gi++) {
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int ii2 = (gBase + gFirst + gi) * 8 + 1 + e, dlt = ii2 - jc;
+                    const bool ok = ii2 >= 1 && ii2 <= m && jc >= 1 && jc <= n && dlt < swBand && -dlt < swBand;
+                    d[e >> 1] |= (ok ? raw[gi * 8 + e] : 0u) << ((e & 1) * 16);
+                }
+                v[0][gi] = u32x4{d[0], d[1], d[2], d[3]};
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < PLANES; pl++) {
+#pragma unroll
+                for (int gi = 0; gi < CNT; gi++) {
+                    const int grp = gBase + gFirst + gi, k = (pl * CNT + gi) * 4;
+                    const bool ok = grp >= 0 && grp * 8 < m && jc >= 1 && jc <= n;
+                    v[pl][gi] = ok ? u32x4{raw[k], raw[k + 1], raw[k + 2], raw[k + 3]} : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        { const int qi = r0 + lane; chQ = (lane < WR && qi >= 0 && qi < m) ? rawQ : 0u; } /* query character of row r0 + 1 + lane */
+        chR = (jc >= 1 && jc <= n) ? rawR : 0u;
         if (algo != DPX_K_LSW) { /* the borders of H as cells: column 0 and row 0 (LSW: zeros, as loaded) */
 #pragma unroll
-            for (int gi = 0; gi < G; gi++) {
+            for (int gi = 0; gi < CNT; gi++) {
                 const int grp = gBase + gFirst + gi;
-                if (gi < gCount && (jc == 0 || grp < 0)) {
+                if (jc == 0 || grp < 0) {
                     uint32_t d[4];
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const int r0 = grp * 8 + 1 + e, r1 = r0 + 1;
-                        const int v0 = jc == 0 ? (r0 >= 0 ? bval(r0) : 0) : (r0 == 0 && jc > 0 ? bval(jc) : 0);
-                        const int v1 = jc == 0 ? (r1 >= 0 ? bval(r1) : 0) : (r1 == 0 && jc > 0 ? bval(jc) : 0);
+                        const int r0b = grp * 8 + 1 + e, r1b = r0b + 1;
+                        const int v0 = jc == 0 ? (r0b >= 0 ? bval(r0b) : 0) : (r0b == 0 && jc > 0 ? bval(jc) : 0);
+                        const int v1 = jc == 0 ? (r1b >= 0 ? bval(r1b) : 0) : (r1b == 0 && jc > 0 ? bval(jc) : 0);
                         d[e >> 1] = ((uint32_t)(uint16_t)v1 << 16) | (uint32_t)(uint16_t)v0;
                     }
                     v[0][gi] = u32x4{d[0], d[1], d[2], d[3]};
@@ -2623,8 +2693,44 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
 #pragma unroll
         for (int pl = 0; pl < PLANES; pl++)
 #pragma unroll
-            for (int gi = 0; gi < G; gi++)
-                if (gi < gCount) *reinterpret_cast<u32x4 *>(win + (pl * 64 + lane) * CS + (gFirst + gi) * 8) = v[pl][gi];
+            for (int gi = 0; gi < CNT; gi++) *reinterpret_cast<u32x4 *>(win + (pl * 64 + lane) * CS + (gFirst + gi) * 8) = v[pl][gi];
+    };
+    /* first fetched row group (relative to the window's first) of this lane's column in a banded window whose last column holds the
+     * diagonal's row iiDiag */
+    auto band_first = [&](const int iiDiag, const int r0) -> int {
+        const int dl = (iiDiag - r0 - 1) - 63 + lane;
+        return min(max((dl - 8) >> 3, 0), G - GL);
+    };
+    constexpr int kRawFull = BAND ? G * 8 : PLANES * G * 4, kRawBand = BAND ? GL * 8 : PLANES * GL * 4;
+    using std::integral_constant;
+    auto load_window = [&](const int ii, const int jj) {
+        const int gBase = ((ii - 1) >> 3) - (G - 1);
+        R0 = gBase * 8;
+        cLo = jj - 63;
+        const int jc = cLo + lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); /* the previous window's reads are done before it is overwritten (LDS only: the walk's byte stores are not waited for) */
+        __builtin_amdgcn_wave_barrier();
+        diag0 = ii - jj;
+        banded = !wantFull;
+        const int gFirst = banded ? band_first(ii, R0) : 0;
+        uint32_t rq, rr;
+        auto both = [&](auto kindC, auto cntC, auto &raw) {
+            issue(kindC, cntC, raw, rq, rr, gBase, gFirst, jc, R0);
+            commit(kindC, cntC, raw, rq, rr, gBase, gFirst, jc, R0);
+        };
+        if (banded) {
+            uint32_t raw[kRawBand];
+            if constexpr (BAND) both(integral_constant<int, 3>{}, integral_constant<int, GL>{}, raw);
+            else if (kind == 0) both(integral_constant<int, 0>{}, integral_constant<int, GL>{}, raw);
+            else if (kind == 1) both(integral_constant<int, 1>{}, integral_constant<int, GL>{}, raw);
+            else both(integral_constant<int, 2>{}, integral_constant<int, GL>{}, raw);
+        } else {
+            uint32_t raw[kRawFull];
+            if constexpr (BAND) both(integral_constant<int, 3>{}, integral_constant<int, G>{}, raw);
+            else if (kind == 0) both(integral_constant<int, 0>{}, integral_constant<int, G>{}, raw);
+            else if (kind == 1) both(integral_constant<int, 1>{}, integral_constant<int, G>{}, raw);
+            else both(integral_constant<int, 2>{}, integral_constant<int, G>{}, raw);
+        }
         /* the two characters are needed HERE: without this the compiler waits for them (s_waitcnt vmcnt(0)) where the walk first uses them --
          * in every trip of the loop, where the wait also covers the byte stores of the previous trips (3 us per trip, measured) */
         asm volatile("" : "+v"(chQ), "+v"(chR));
@@ -2729,7 +2835,19 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
             int qc;
             const uint32_t d = decide_diag(r, c, qc);
             const int run = run_down(d == 0u, c);
-            if (run) { emit_diag(c, run, qc); i -= run; j -= run; continue; }
+            if (run) {
+                /* ... and the step that ends the run with it: the lane below the run has decided that cell already (paths of related
+                 * sequences are diagonal runs separated by single gap steps: half the trips) */
+                emit_diag(c, run, qc); i -= run; j -= run;
+                const int cx = c - run, rx = r - run;
+                if (cx >= 1 && rx >= 1 && i > 0 && j > 0) {
+                    const uint32_t dx = (uint32_t)__builtin_amdgcn_readlane((int)d, cx);
+                    if (dx == 1u) { emit_up(rx, 1); i--; }
+                    else if (dx == 2u) { emit_left(cx, 1); j--; }
+                    else if (algo == DPX_K_LSW) break; /* H = 0: the local alignment starts here */
+                }
+                continue;
+            }
             const uint32_t dc = (uint32_t)__builtin_amdgcn_readlane((int)d, c);
             if (algo == DPX_K_LSW && dc == 3u) break;
             const int dev = (i - j) - diag0;
@@ -2745,7 +2863,12 @@ __global__ void __launch_bounds__(64) k_traceback_wave(const dpx_fill_args a, in
                 int qc;
                 const uint32_t d = decide_diag(r, c, qc);
                 const int run = run_down(d == 0u, c);
-                if (run) { emit_diag(c, run, qc); i -= run; j -= run; continue; }
+                if (run) {
+                    emit_diag(c, run, qc); i -= run; j -= run;
+                    const int cx = c - run, rx = r - run; /* the cell that ends the run has been decided with it */
+                    if (cx >= 1 && rx >= 1 && i > 0 && j > 0) { const int dx = __builtin_amdgcn_readlane((int)d, cx); if (dx == 1 || dx == 2) cur = dx; }
+                    continue;
+                }
                 cur = __builtin_amdgcn_readlane((int)d, c); /* 1: to INSERTION, 2: to DELETION */
             } else if (cur == 1) {
                 /* INSERTION: steps to the left along row r until (and including) the cell where the gap was opened; lane l decides the cell in column l */
@@ -3164,12 +3287,16 @@ hipError_t dpx_launch_traceback(const dpx_fill_args &a, int numPairs, int algo, 
                                 const uint64_t *tbOff, char *tb, int32_t *tbLen, hipStream_t stream) {
     if (numPairs <= 0) return hipSuccess;
     const bool cachedWalk = walk == 1;
-    if (walk == 2 && algo != DPX_K_BSW) { /* one wave per pair with an LDS window (k_traceback_wave) */
+    if (walk == 2) { /* one wave per pair with an LDS window (k_traceback_wave) */
         const size_t lds = dpx_traceback_wave_lds(algo == DPX_K_ANW ? 3 : 1);
         if (algo == DPX_K_ANW)
-            hipLaunchKernelGGL(k_traceback_wave<3>, dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, algo, R, a.endRow, a.endCol, tbOff, tb, tbLen);
+            hipLaunchKernelGGL((k_traceback_wave<3, false, DPX_K_ANW>), dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, R, a.endRow, a.endCol, tbOff, tb, tbLen);
+        else if (algo == DPX_K_BSW)
+            hipLaunchKernelGGL((k_traceback_wave<1, true, DPX_K_LSW>), dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, R, a.endRow, a.endCol, tbOff, tb, tbLen);
+        else if (algo == DPX_K_LNW)
+            hipLaunchKernelGGL((k_traceback_wave<1, false, DPX_K_LNW>), dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, R, a.endRow, a.endCol, tbOff, tb, tbLen);
         else
-            hipLaunchKernelGGL(k_traceback_wave<1>, dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, algo, R, a.endRow, a.endCol, tbOff, tb, tbLen);
+            hipLaunchKernelGGL((k_traceback_wave<1, false, DPX_K_LSW>), dim3((unsigned)numPairs), dim3(64), lds, stream, a, numPairs, R, a.endRow, a.endCol, tbOff, tb, tbLen);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)((numPairs + 63) / 64)), dim3(64), 0, stream, a, numPairs, algo, R, planes,

@@ -72,6 +72,32 @@ def test_banded_traceback_vs_oracle(gpu):
             assert b.traceback(p) == want, p
 
 
+@pytest.mark.parametrize("walk", ["0", "2"])
+@pytest.mark.parametrize("band", [1, 5, 24, 64, 100, 200, 300, 512])
+def test_banded_walks_on_every_band_width(gpu, band, walk, monkeypatch):
+    """Round 4: banded matrices are walked by one wave per pair too (k_traceback_wave<1, true>: the window is gathered from the
+    anti-diagonal-major band layout, 1 / 2 / 4 / 8 cells per lane).  Every band-layout variant, paths that run along the band's
+    edge (shifted copies), windows crossed by long gaps, ragged and empty pairs -- every printed line against the oracle, for the
+    wave walk (the default) and the lane walk."""
+    monkeypatch.setenv("DPX_TB_WALK", walk)
+    import numpy as np
+    rng = np.random.default_rng(band)
+    core = "".join("0123"[x] for x in rng.integers(0, 4, 700))
+    shift = min(band - 1, 40)
+    sbs = [make_batch(4, 700, 650, seed=71 + band, first_index=97),
+           make_ragged_batch(12, 1, 400, 1, 380, seed=72 + band),
+           from_strings([(core, core), (core[shift:], core), (core, core[shift:]), (core[:300] + core[300 + shift // 2:], core),
+                         (core, core[:200] + core[200 + shift // 2:]), ("", "0123"), ("0123", ""), ("3", "0123012301230123"),
+                         ("0" * 300, "1" * 200 + "0" * 90), ("0" * 90, "0" * 90)])]
+    for sb in sbs:
+        with gpu.Batch(gpu.ALGO_BSW, sb.sequences, sb.pairs, 3, -1, -2, band=band) as b:
+            b.fill()
+            for p in range(sb.num_pairs):
+                o = O.lsw(sb.ref(p), sb.qry(p), 3, -1, -2, band=band)
+                want = ("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)
+                assert b.traceback(p) == want, (band, walk, p, len(sb.qry(p)), len(sb.ref(p)))
+
+
 @pytest.mark.parametrize("cached", ["0", "1", "2"])
 @pytest.mark.parametrize("algo", ["LSW", "LNW"])
 def test_all_walks_print_the_same_lines(gpu, algo, cached, monkeypatch):
