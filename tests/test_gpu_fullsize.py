@@ -81,13 +81,13 @@ def test_config2_anw_1k_1024(gpu):
         assert np.all(er == 1024) and np.all(ec == 1024)
         for p in _ident(sb):
             assert sc[p] == 3 * 1024
-        for p in range(0, 1000, 8):                                          # 125 pairs, score + (some) all three matrices
-            o = O.anw(sb.ref(p), sb.qry(p), *w, want_dir=(p % 200 == 0))
+        for p in range(0, 1000):                                             # every pair: score and printed lines; every 8th all three matrices (round 3: 125 scores, 5 x 3 matrices)
+            o = O.anw(sb.ref(p), sb.qry(p), *w, want_dir=True)
             assert sc[p] == o.score, p
-            if p % 200 == 0:
+            assert b.traceback(p) == O.anw_traceback(sb.ref(p), sb.qry(p), o), p
+            if p % 8 == 0:
                 for which, want in ((gpu.MAT_H, o.H), (gpu.MAT_I, o.I), (gpu.MAT_D, o.D)):
-                    assert np.array_equal(b.matrix(p, which).astype(np.int32), want)
-                assert b.traceback(p) == O.anw_traceback(sb.ref(p), sb.qry(p), o)
+                    assert np.array_equal(b.matrix(p, which).astype(np.int32), want), (p, which)
 
 
 def test_config3_banded_10k_4096_band128(gpu):
@@ -103,9 +103,11 @@ def test_config3_banded_10k_4096_band128(gpu):
         for p in list(range(3, 10000, 20)) + sample:                         # 1,028,224 in-band cells per pair (round 3: 504 pairs, was 44)
             o = O.lsw(sb.ref(p), sb.qry(p), *W, band=128, want_dir=False)
             assert (sc[p], er[p], ec[p]) == (o.score, o.end_row, o.end_col), p
-        o = O.lsw(sb.ref(97), sb.qry(97), *W, band=128)
-        assert np.array_equal(b.matrix(97).astype(np.int32), o.H)
-        assert b.traceback(97) == (("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(97), sb.qry(97), o))
+        for p in [0, 96, 97, 100, 4242, 9999] + list(range(50, 10000, 250)):    # printed lines of 46 pairs (the wave walk over the band layout; round 3: 1),
+            o = O.lsw(sb.ref(p), sb.qry(p), *W, band=128)                       # every cell of 6 whole matrices (round 3: 1) -- a random pair, a copy, mutated ones
+            assert b.traceback(p) == (("", "", "") if o.score == 0 else O.lsw_traceback(sb.ref(p), sb.qry(p), o)), p
+            if p in (0, 96, 97, 100, 4242, 9999):
+                assert np.array_equal(b.matrix(p).astype(np.int32), o.H), p
     # restricting the paths can only lower a local score: banded <= unbanded, pair by pair
     seqs, prs = _sub(sb, sample)
     with gpu.Batch(gpu.ALGO_LSW, seqs, prs, *W) as full:
