@@ -119,7 +119,8 @@ int main(int argc, char *argv[]) {
     const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
     std::thread reserve;
     // (and three pinned text buffers: one being printed, two batches in flight)
-    if (batchSize == 0) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 3); });
+    const bool budgetedBatches = batchSize == 0;
+    if (budgetedBatches) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 3); });
 
     printf("Parsing input file: %s\n", pairFileName);
     seqPair *sequenceIdxs;
@@ -152,6 +153,13 @@ int main(int argc, char *argv[]) {
         else if (rc != DPX_OK) die("FAILED TO PACK THE SEQUENCES", rc);
     }
     if (reserve.joinable()) reserve.join();
+    // Producer threads (below) keep one batch more alive than -inflight says; without a pool of its own that batch would build one inside
+    // the timed region (a 4-GiB pool: 100 - 450 ms, seen with -producer 2 on long pairs; a short-read pool: a few ms of the job's six).
+    const int producers = producerFlag >= 0 ? std::min(producerFlag, 8) : (batchSize >= 8192 ? 2 : 0);
+    if (budgetedBatches && producers > 0 && producers + 1 > inflight) {
+        (void)dpx_pool_reserve(poolBudget, std::min(8, producers + 1));
+        if (print) (void)dpx_text_reserve((size_t)16 << 20, std::min(9, producers + 1 + 3));
+    }
     start_timer();
     uint64_t kernel_time = 0, memalloc_time = 0, backtracking_time = 0, printing_time = 0; // usec, as V19.cu:411-415
     uint64_t traceback_kernel_time = 0; // device time of the traceback + text kernels (backtracking_time is the host's wait for them)
@@ -229,7 +237,6 @@ int main(int argc, char *argv[]) {
     // and fills the batch and starts its output, this thread finishes the batches in input order.  At most -inflight batches exist
     // between the one being finished and the newest one being created.  Batches of few long pairs are bound by the device, and there one
     // issuing thread is as fast or faster (10000 x 1024^2: 8.1-8.9 vs 8.4-9.3 ms).  -producer 0 turns the threads off.
-    const int producers = producerFlag >= 0 ? std::min(producerFlag, 8) : (batchSize >= 8192 ? 2 : 0);
     if (producers > 0) {
         const size_t numBatches = (shardHi - shardLo + batchSize - 1) / batchSize;
         if ((size_t)producers + 1 > maxAlive) maxAlive = std::min<size_t>(8, (size_t)producers + 1); // (every producer needs a slot of its own)
