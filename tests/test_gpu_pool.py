@@ -1,6 +1,8 @@
 """Round 3: the matrix pool is a chunked virtual range (hipMemAddressReserve + hipMemCreate + hipMemMap) for every caller, with a
 record of how it was built and timed in dpx_batch_describe; DPX_TUNE_PLACEMENT shops for a pool with the batch's own fill;
 dpx_pool_reserve builds pools ahead of time.  Results never depend on any of it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -47,6 +49,8 @@ def test_small_pools_stay_on_hipmalloc(gpu):
 
 
 def test_tuned_placement_records_every_candidate(gpu):
+    if os.environ.get("DPX_POOL_GUARD"):
+        pytest.skip("no pool is timed or shopped for under the guard band (the memset probe would wipe it)")
     gpu.load().dpx_shutdown(); gpu.init(0)
     sb = make_batch(1200, 1024, 1024, seed=22)                   # 2.7 GB pool: above the 1-GiB floor of the tuning
     d, res, _ = _fill(gpu, sb, flags=gpu.TUNE_PLACEMENT)
