@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two `gloo` ranks shard a batch, each fills its shard, rank 0 gathers the scores with the same
+"""N>1 path on CPU: two and eight `gloo` ranks shard a batch, each fills its shard, rank 0 gathers the scores with the same
 dpx_gpu_genomics_project_amd.shard helpers bench.py uses under RCCL.  The per-shard compute here is the CPU oracle
 (this is a test of the sharding + collective plumbing; the GPU fill itself is covered by the -m gpu tests)."""
 import os
@@ -44,14 +44,16 @@ def _worker(rank, world, port, num_pairs, ragged, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_pairs,ragged", [(24, False), (25, True)])
-def test_two_rank_shard_and_gather(tmp_path, num_pairs, ragged):
+@pytest.mark.parametrize("world,num_pairs,ragged", [(2, 24, False), (2, 25, True), (8, 64, False), (8, 61, True)])
+def test_shard_and_gather_over_gloo(tmp_path, world, num_pairs, ragged):
+    """World sizes 2 and 8 (the node the scaling run uses): even shards through dist.gather, ragged ceil(N/G) shards (the last rank short,
+    as configs[4] would be on 7 GPUs) through the padded gather."""
     sys.path.insert(0, HERE)
     import oracle_py as O
     from dpx_gpu_genomics_project_amd.synth import make_batch
 
     out = str(tmp_path / "scores.npy")
-    mp.spawn(_worker, args=(2, _free_port(), num_pairs, ragged, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), num_pairs, ragged, out), nprocs=world, join=True)
     got = np.load(out)
     sb = make_batch(num_pairs, 40, 56, seed=77)
     want = np.array([O.lsw(sb.ref(p), sb.qry(p), want_dir=False).score for p in range(num_pairs)], np.int32)
