@@ -31,7 +31,7 @@ void BandedSmithWaterman::align() {
 }
 
 void BandedSmithWaterman::print_results() {
-    PrintGuard stdoutIsMine; // lock ... fflush ... unlock, as the other aligners do by hand
+    PrintGuard stdoutIsMine; // lock ... unlock, as the other aligners do by hand
     if (max_score == 0) printf("%d | 0\n\n\n\n", pairNum);
     else printf("%d | %d\n%s\n%s\n%s\n", pairNum, max_score, gpu.refLine.c_str(), gpu.relLine.c_str(), gpu.qryLine.c_str());
 }

@@ -9,7 +9,7 @@
 #endif
 
 void printLock();   // blocks until this thread owns stdout
-void printUnlock(); // releases it (call after fflush(stdout))
+void printUnlock(); // releases it
 
 // scope guard for new code: { PrintGuard g; printf(...); } -- flushes before it lets go
 struct PrintGuard {
