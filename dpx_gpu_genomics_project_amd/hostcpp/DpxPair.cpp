@@ -115,8 +115,13 @@ void initDevices() { // under g_mu
     if (const char *env = getenv("DPX_CLASS_LEADERS")) { const int v = atoi(env); if (v >= 1 && v <= 64) g_maxLeaders = v; }
 }
 
+size_t g_crowd = 0; // callers the last gather window ended with
+
 void gatherWindow(std::unique_lock<std::mutex> &lk) {
-    // wait while callers keep arriving: stop after 40 us without a new request, 400 us in total at most
+    // Wait while callers keep arriving: stop after 40 us without a new request, 400 us in total at most -- or after 8 us without one when
+    // as many have arrived as the last window ended with (the reference's driver runs a fixed number of threads in lockstep: the crowd
+    // is complete, but a late-comer inside those 8 us still grows it; when threads retire the 40-us rule shrinks it again).  Round 4:
+    // without the 8 us of grace the crowd only ever shrank (417 device round trips instead of 241 for 4000 pairs).
     using clock = std::chrono::steady_clock;
     const auto t0 = clock::now();
     auto lastArrival = t0;
@@ -127,8 +132,11 @@ void gatherWindow(std::unique_lock<std::mutex> &lk) {
         lk.lock();
         const auto now = clock::now();
         if (g_queue.size() != seen) { seen = g_queue.size(); lastArrival = now; }
-        if (now - lastArrival > std::chrono::microseconds(40) || now - t0 > std::chrono::microseconds(400)) return;
+        const auto quiet = now - lastArrival;
+        if (quiet > std::chrono::microseconds(40) || now - t0 > std::chrono::microseconds(400)) break;
+        if (g_crowd > 1 && seen >= g_crowd && quiet > std::chrono::microseconds(8)) break;
     }
+    g_crowd = g_queue.size();
 }
 
 } // namespace
