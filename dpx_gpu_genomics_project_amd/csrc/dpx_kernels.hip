@@ -2978,16 +2978,13 @@ __global__ void __launch_bounds__(kScanThreads) k_out_scan_tiles(unsigned long l
     }
 }
 
-/* one wave per pair: header by lane 0, the three right-aligned lines of k_traceback copied 64 bytes per instruction */
-__global__ void __launch_bounds__(256) k_out_compact(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff,
-                                                      const char *tb, int numPairs, unsigned long long firstNumber,
-                                                      const unsigned long long *outOff, char *out) {
-    const int lane = threadIdx.x & 63;
-    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (p >= numPairs) return;
+/* one pair's block, written by one wave: header by lane 0, the three right-aligned lines of k_traceback copied 64 bytes per instruction */
+__device__ __forceinline__ void out_write_block(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff,
+                                                const char *tb, const int p, const int lane, const unsigned long long firstNumber,
+                                                const unsigned long long dstOff, char *out) {
     const int len = tbLen[p], sc = score[p];
     const int cap = (pairs[p].m + pairs[p].n + 1 + 3) & ~3; /* line capacity, as in k_traceback */
-    char *dst = out + outOff[p];
+    char *dst = out + dstOff;
     const unsigned long long number = firstNumber + (unsigned long long)p;
     const unsigned us = sc < 0 ? 0u - (unsigned)sc : (unsigned)sc;
     const int dn = dec_digits(number), ds = dec_digits(us), neg = sc < 0 ? 1 : 0;
@@ -3009,6 +3006,36 @@ __global__ void __launch_bounds__(256) k_out_compact(const dpx_pair_dev *pairs, 
         for (int x = lane; x < len; x += 64) d[x] = s[x];
         if (lane == 0) d[len] = '\n';
     }
+}
+
+__global__ void __launch_bounds__(256) k_out_compact(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff,
+                                                      const char *tb, int numPairs, unsigned long long firstNumber,
+                                                      const unsigned long long *outOff, char *out) {
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (p >= numPairs) return;
+    out_write_block(pairs, score, tbLen, tbOff, tb, p, lane, firstNumber, outOff[p], out);
+}
+
+/* Small batches (up to kOutSmallPairs pairs: the class-per-pair drivers send 20 per device round trip): lengths, scan and copy in ONE
+ * workgroup -- one launch instead of four in a chain of dependent kernels whose launches are most of the round trip. */
+constexpr int kOutSmallPairs = 256;
+static_assert(kOutSmallPairs <= kScanThreads, "one pair per thread");
+__global__ void __launch_bounds__(kScanThreads) k_out_small(const dpx_pair_dev *pairs, const int32_t *score, const int32_t *tbLen, const uint64_t *tbOff,
+                                                            const char *tb, int numPairs, unsigned long long firstNumber, unsigned long long *outOff,
+                                                            char *out) {
+    __shared__ unsigned long long lds[kScanThreads / 64];
+    __shared__ unsigned long long offs[kOutSmallPairs];
+    const int p = (int)threadIdx.x; /* one pair per thread (kScanThreads >= kOutSmallPairs) */
+    const unsigned long long mine = p < numPairs ? block_len(firstNumber + (unsigned long long)p, score[p], tbLen[p]) : 0ull;
+    unsigned long long total;
+    const unsigned long long ex = group_exclusive(mine, lds, &total);
+    if (p < numPairs) { outOff[p] = ex; offs[p] = ex; }
+    if (p == 0) outOff[numPairs] = total;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); q < numPairs; q += kScanThreads / 64)
+        out_write_block(pairs, score, tbLen, tbOff, tb, q, lane, firstNumber, offs[q], out);
 }
 
 /* =====================================================================================================
@@ -3312,6 +3339,10 @@ hipError_t dpx_launch_output(const dpx_pair_dev *pairs, const int32_t *score, co
                              bool scanOnly, bool compactOnly, hipStream_t stream) {
     if (numPairs <= 0) return hipSuccess;
     const int tiles = (int)dpx_out_scan_tiles((size_t)numPairs);
+    if (!compactOnly && !scanOnly && numPairs <= kOutSmallPairs) {
+        hipLaunchKernelGGL(k_out_small, dim3(1), dim3(kScanThreads), 0, stream, pairs, score, tbLen, tbOff, tb, numPairs, firstNumber, outOff, out);
+        return hipGetLastError();
+    }
     if (!compactOnly) {
         hipLaunchKernelGGL(k_out_scan<false>, dim3(tiles), dim3(kScanThreads), 0, stream, score, tbLen, numPairs, firstNumber, tileSums, outOff);
         hipLaunchKernelGGL(k_out_scan_tiles, dim3(1), dim3(kScanThreads), 0, stream, tileSums, tiles);
