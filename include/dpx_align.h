@@ -141,7 +141,9 @@ int dpx_batch_create_packed2(int device, const dpx_params *params, const uint8_t
  * `smith_waterman_kernel<<<1,32>>>` (cuda/LinearSmithWaterman.cu:263) and
  * `affine_needleman_wunsch_kernel<<<1,32>>>` (cuda/AffineNeedlemanWunsch.cu:338).  May be called repeatedly.
  * A caller-owned stream must stay valid until the batch has been synchronised or destroyed: dpx_batch_destroy()
- * waits on the stream of the last fill before it parks the batch's buffers for reuse by the next batch. */
+ * waits on the stream of the last fill before it parks the batch's buffers for reuse by the next batch.
+ * (The inputs of a small batch are still on their way when dpx_batch_create() returns -- one asynchronous copy on the batch's own
+ * stream; the first fill on a caller's stream waits for it on the host, fills on the batch's stream are simply ordered behind it.) */
 int dpx_batch_fill(dpx_batch *b, void *stream);
 
 /* Run `repeats` fills back-to-back and return the mean device time of one fill in microseconds, measured with
