@@ -13,11 +13,10 @@
 // Batch size: by default from a matrix-pool BUDGET (-pool-gb, 4 GiB): as many pairs as fit the budget, at most 20000 (the
 // reference sizes its buffers once for BATCH_SIZE = 10000 reads of 150 bases, cuda/LNW/LinearNeedlemanWunschV9.cu:26-46,
 // V14.cu:144-213 -- 10000 pairs of 1024 x 1024 would be a 22 GB pool whose allocation costs 50 times the fill).  -inflight such
-// pools (default 6, at most 8) are built on a helper thread while the file is being parsed and then recycled by every batch: that many
-// batches are on the device at a time.  Round 4 (profiles/r04/e2e_long_timeline_*.txt): a batch of 1700 pairs of 1024 x 1024 is a chain
-// of latency-bound kernels -- its fill keeps 0.8 waves per SIMD busy for 0.6 ms, the walks of its traceback 1.7 waves for 0.5 ms --
-// and with two batches in flight the device idled between the chains (9.1 ms for 10 000 pairs, of which the device worked 7.5); with
-// six the fills of the later batches run under the tracebacks of the earlier ones.
+// pools (default 3, at most 8) are built on a helper thread while the file is being parsed and then recycled by every batch: that many
+// batches are on the device at a time.  Round 4 (profiles/r04/e2e_*.txt): a batch of 1700 pairs of 1024 x 1024 is a chain fill -> traceback
+// -> text -> copy of ~1.5 ms; with two in flight the device idles while this thread creates the next batch (7.1 - 7.9 ms for 10 000 pairs),
+// with three the next fill is already queued (6.6 - 7.4 ms); deeper pipelines only add fills that share the same HBM (4 ... 8: slower again).
 //
 // Multi-GPU: pairs are independent, so every GPU gets one process with its own contiguous shard of the file:
 // `-rank r -world w` aligns only pairs [ceil(N/w)*r, ceil(N/w)*(r+1)) (the same split as shard.py / bench.py) and
@@ -66,7 +65,7 @@ int main(int argc, char *argv[]) {
     double poolGb = 4.0;
     bool print = true, pack2 = false;
     int producerFlag = -1; // producer threads; -1: by batch size (2 for batches of many short pairs, none for few long ones)
-    int inflight = 2;      // batches on the device at a time (= matrix pools reserved)
+    int inflight = 3;      // batches on the device at a time (= matrix pools reserved)
     int tuneFlag = -1;     // -1: by the length of the job
     std::string algoName = "LSW";
     for (int i = 1; i < argc; i++) {
@@ -118,7 +117,7 @@ int main(int argc, char *argv[]) {
     // as many pairs -- and fills the chip as well -- as a linear-gap batch of the same shapes)
     const size_t poolBudget = (size_t)(poolGb * (double)(1ull << 30)) * (algo == DPX_ALGO_ANW ? 3 : 1);
     std::thread reserve;
-    // (and three pinned text buffers: one being printed, two batches in flight)
+    // (and pinned text buffers: one being printed, one per batch in flight, two spare)
     const bool budgetedBatches = batchSize == 0;
     if (budgetedBatches) reserve = std::thread([poolBudget, print, inflight]() { (void)dpx_pool_reserve(poolBudget, inflight); if (print) (void)dpx_text_reserve((size_t)16 << 20, inflight + 3); });
 
