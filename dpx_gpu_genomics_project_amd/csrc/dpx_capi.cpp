@@ -58,6 +58,7 @@ int bind_device(int device = -1) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kSmallResultBytes = 12288; /* score / end row / end column of a small batch, as they lie in the arena (dpx_batch_output_begin) */
 
 /* Development and test knobs.  The environment is read in ONE place, when dpx_init() binds a device and again at the start of every
  * dpx_batch_create*() (the tests flip a knob between two batches of one process); everything else reads this snapshot.  -1 / 0 = not
@@ -527,6 +528,7 @@ struct dpx_batch {
     char *dOut = nullptr;
     char *hStage = nullptr; /* pinned image of the arena's uploaded front (small batches), alive until the batch is destroyed */
     size_t hStageCap = 0;
+    bool resultsCopied = false; /* ... and of score / end row / end column, into the tail of hMeta */
     bool textCopied = false;    /* dpx_batch_output_begin() has queued the text's D2H itself (small batches) */
     bool uploadPending = false; /* ... and its one asynchronous H2D on b->stream has not been waited for by anybody yet */
     std::vector<uint64_t> tbOff;
@@ -1721,6 +1723,13 @@ int dpx_batch_results(dpx_batch *b, int32_t *scores, int32_t *endRow, int32_t *e
     HIP_TRY(hipStreamSynchronize(b->stream));
     const size_t bytes = b->numPairs * sizeof(int32_t);
     const size_t stride = (size_t)((const char *)b->dEndRow - (const char *)b->dScore); /* the three arrays follow each other in the arena */
+    if (bytes && b->resultsCopied && b->outState != 0 && b->hMeta) { /* dpx_batch_output_begin() brought them along (small batches) */
+        const char *tail = b->hMeta + (b->numPairs + 1) * sizeof(uint64_t) + b->numPairs * sizeof(int32_t) + 16;
+        if (scores) memcpy(scores, tail, bytes);
+        if (endRow) memcpy(endRow, tail + stride, bytes);
+        if (endCol) memcpy(endCol, tail + 2 * stride, bytes);
+        return check_guard(b);
+    }
     if (bytes && scores && endRow && endCol && (const char *)b->dEndCol - (const char *)b->dEndRow == (ptrdiff_t)stride && 3 * stride <= 12288) {
         /* small batches (the class-per-pair drivers: 20 pairs per round trip): one copy instead of three -- a synchronous copy costs
          * ~15 us whatever its size */
@@ -1775,7 +1784,7 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
         if (!b->dTb) HIP_TRY(g_tbDevCache.take((void **)&b->dTb, (size_t)std::max<uint64_t>(lines, 16), &b->dTbCap));
         /* packed text, worst case: every alignment m + n long, 20 digits of pair number, 11 of score */
         if (!b->dOut) HIP_TRY(g_tbDevCache.take((void **)&b->dOut, (size_t)(lines + 40ull * np + 16), &b->dOutCap));
-        if (!b->hMeta) HIP_TRY(g_tbHostCache.take((void **)&b->hMeta, (np + 1) * sizeof(uint64_t) + np * sizeof(int32_t) + 16, &b->hMetaCap));
+        if (!b->hMeta) HIP_TRY(g_tbHostCache.take((void **)&b->hMeta, (np + 1) * sizeof(uint64_t) + np * sizeof(int32_t) + 16 + kSmallResultBytes, &b->hMetaCap));
         trace.mark("output: buffers");
     }
     uint64_t *hOff = reinterpret_cast<uint64_t *>(b->hMeta);
@@ -1812,6 +1821,7 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
                               false, false, b->stream));
     if (timeOut) { HIP_TRY(hipEventRecord(b->evOut1, b->stream)); b->outTimed = true; }
     b->textCopied = false;
+    b->resultsCopied = false;
     if (np) {
         HIP_TRY(hipMemcpyAsync(hOff, b->dOutOff, (np + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipMemcpyAsync(hLen, b->dTbLen, np * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
@@ -1826,6 +1836,15 @@ static int output_begin(dpx_batch *b, uint64_t firstNumber) {
             }
             HIP_TRY(hipMemcpyAsync(b->hOut, b->dOut, worst, hipMemcpyDeviceToHost, b->stream));
             b->textCopied = true;
+            /* ... and so do score / end row / end column (they lie side by side in the arena): dpx_batch_results() after this call is a
+             * wait and three memcpy instead of a wait and a synchronous copy of its own */
+            const size_t stride = (size_t)((const char *)b->dEndRow - (const char *)b->dScore), bytes = np * sizeof(int32_t);
+            if ((const char *)b->dEndCol - (const char *)b->dEndRow == (ptrdiff_t)stride && 2 * stride + bytes <= kSmallResultBytes &&
+                (!b->lastStream || b->lastStream == b->stream)) {
+                char *tail = b->hMeta + (np + 1) * sizeof(uint64_t) + np * sizeof(int32_t) + 16;
+                HIP_TRY(hipMemcpyAsync(tail, b->dScore, 2 * stride + bytes, hipMemcpyDeviceToHost, b->stream));
+                b->resultsCopied = true;
+            }
         }
     } else {
         hOff[0] = 0;
